@@ -1,0 +1,323 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ *
+ * Plain-C, single-threaded, float32 restatement of the geometry / index half of the
+ * ConTEXTure per-view painting path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this file's shared object.
+ *
+ * Built with  gcc -O2 -ffp-contract=off  so every float op is a single IEEE-754 binary32
+ * operation in source order; the HIP kernels are compiled with contraction off too, which is
+ * what makes bit-exact comparison (face index AND interpolated floats) meaningful.
+ *
+ * What each function restates (reference file:line -> third-party contract):
+ *   orc_prepare_vertices  : src/models/render.py:112-113, src/models/textured_mesh.py:167-168
+ *                           -> kaolin 0.15.0 render.mesh.prepare_vertices
+ *   orc_rasterize         : src/models/render.py:115-120, textured_mesh.py:170-175
+ *                           -> kaolin 0.15.0 render.mesh.rasterize, CUDA backend
+ *                              (pixel-parallel brute force over faces in index order)
+ *   orc_normalize_depth   : src/models/render.py:48-74 (normalize_multiple_depth, min_val = 0)
+ *   orc_texture_mapping   : src/models/render.py:135 -> kaolin texture_mapping == grid_sample
+ *                           (bilinear / nearest, align_corners=False, padding_mode='border')
+ *   orc_texture_mapping_bwd : autograd of the above w.r.t. the atlas (SDS loop, trainer.py:866)
+ *   orc_gather_normals    : src/models/render.py:150-157 (face_idx -1 wraps to the LAST face)
+ *   orc_view_weights      : src/training/trainer.py:155-249 (create_face_view_map +
+ *                           compare_face_normals_between_views with torch_scatter.scatter_max)
+ *   orc_raw2outputs       : north_star "alpha-composite"; absent in the reference,
+ *                           follows nerf-pytorch run_nerf.py raw2outputs which
+ *                           src/run_nerf_helpers.py:130-133 cites.
+ *
+ * PARITY UNPINNED for the kaolin-owned pieces: kaolin is not installed and its source is not
+ * under /root/reference, and the reference holds no golden vectors for them.  The raster rule
+ * below is the kaolin 0.15.0 CUDA kernel as published (barycentric solve by Cramer's rule with
+ * k3+eps denominator, half-open bbox test, strict '>' depth test so the lowest face index wins
+ * ties, screen-space (not perspective-correct) interpolation).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+void orc_prepare_vertices(const float *verts, const int64_t *faces, const float *cam,
+                          const float *proj3, int B, int V, int F,
+                          float *fv_cam, float *fv_img, float *fnorm)
+{
+    float *vc = (float *)malloc(sizeof(float) * (size_t)V * 3);
+    float *vi = (float *)malloc(sizeof(float) * (size_t)V * 2);
+    for (int b = 0; b < B; ++b) {
+        const float *M = cam + (size_t)b * 12; /* [4][3] */
+        const float *vb = verts + (size_t)b * V * 3;
+        for (int v = 0; v < V; ++v) {
+            float x = vb[v * 3 + 0], y = vb[v * 3 + 1], z = vb[v * 3 + 2];
+            for (int k = 0; k < 3; ++k) {
+                float acc = x * M[0 * 3 + k];
+                acc = acc + y * M[1 * 3 + k];
+                acc = acc + z * M[2 * 3 + k];
+                acc = acc + M[3 * 3 + k];
+                vc[v * 3 + k] = acc;
+            }
+            float px = vc[v * 3 + 0] * proj3[0];
+            float py = vc[v * 3 + 1] * proj3[1];
+            float pz = vc[v * 3 + 2] * proj3[2];
+            vi[v * 2 + 0] = px / pz;
+            vi[v * 2 + 1] = py / pz;
+        }
+        for (int f = 0; f < F; ++f) {
+            float p[3][3];
+            for (int k = 0; k < 3; ++k) {
+                int64_t vid = faces[(size_t)f * 3 + k];
+                for (int c = 0; c < 3; ++c) {
+                    p[k][c] = vc[vid * 3 + c];
+                    fv_cam[(((size_t)b * F + f) * 3 + k) * 3 + c] = p[k][c];
+                }
+                fv_img[(((size_t)b * F + f) * 3 + k) * 2 + 0] = vi[vid * 2 + 0];
+                fv_img[(((size_t)b * F + f) * 3 + k) * 2 + 1] = vi[vid * 2 + 1];
+            }
+            float e0x = p[1][0] - p[0][0], e0y = p[1][1] - p[0][1], e0z = p[1][2] - p[0][2];
+            float e1x = p[2][0] - p[0][0], e1y = p[2][1] - p[0][1], e1z = p[2][2] - p[0][2];
+            float nx = e0y * e1z - e0z * e1y;
+            float ny = e0z * e1x - e0x * e1z;
+            float nz = e0x * e1y - e0y * e1x;
+            float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+            float d = len + 1e-10f;
+            fnorm[((size_t)b * F + f) * 3 + 0] = nx / d;
+            fnorm[((size_t)b * F + f) * 3 + 1] = ny / d;
+            fnorm[((size_t)b * F + f) * 3 + 2] = nz / d;
+        }
+    }
+    free(vc);
+    free(vi);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* One face against one pixel.  Returns 1 and fills w[3], z when the pixel is covered. */
+static inline int cover(const float *xy6, const float *z3, float x0, float y0, float eps,
+                        float *w, float *zout)
+{
+    float ax = xy6[0], ay = xy6[1], bx = xy6[2], by = xy6[3], cx = xy6[4], cy = xy6[5];
+    float xmin = fminf(fminf(ax, bx), cx), xmax = fmaxf(fmaxf(ax, bx), cx);
+    float ymin = fminf(fminf(ay, by), cy), ymax = fmaxf(fmaxf(ay, by), cy);
+    if (x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax) return 0;
+    float m = bx - ax, p = by - ay, n = cx - ax, q = cy - ay, s = x0 - ax, t = y0 - ay;
+    float k1 = s * q - n * t;
+    float k2 = m * t - s * p;
+    float k3 = m * q - n * p;
+    float den = k3 + eps;
+    float w1 = k1 / den;
+    float w2 = k2 / den;
+    float w0 = (1.0f - w1) - w2;
+    if (w0 < 0.0f || w1 < 0.0f || w2 < 0.0f) return 0;
+    /* NaN weights (den == 0) fail no '<' test; they are rejected by the z test below because
+       NaN > x is false — identical on the GPU. */
+    float z = (w0 * z3[0] + w1 * z3[1]) + w2 * z3[2];
+    w[0] = w0; w[1] = w1; w[2] = w2;
+    *zout = z;
+    return 1;
+}
+
+void orc_rasterize(int H, int W, const float *fz, const float *fxy, const float *feat,
+                   int B, int F, int C, float multiplier, float eps,
+                   float *out, int64_t *face_idx)
+{
+    float *sxy = (float *)malloc(sizeof(float) * (size_t)F * 6);
+    for (int b = 0; b < B; ++b) {
+        const float *xyb = fxy + (size_t)b * F * 6;
+        for (size_t i = 0; i < (size_t)F * 6; ++i) sxy[i] = xyb[i] * multiplier;
+        const float *zb = fz + (size_t)b * F * 3;
+        const float *fb = feat + (size_t)b * F * 3 * C;
+        for (int j = 0; j < H; ++j) {
+            float y0 = (multiplier / (float)H) * (float)(H - 2 * j - 1);
+            for (int i = 0; i < W; ++i) {
+                float x0 = (multiplier / (float)W) * (float)(2 * i + 1 - W);
+                float best = -INFINITY, bw[3] = {0, 0, 0};
+                int64_t bi = -1;
+                for (int f = 0; f < F; ++f) {
+                    float w[3], z;
+                    if (!cover(sxy + (size_t)f * 6, zb + (size_t)f * 3, x0, y0, eps, w, &z)) continue;
+                    if (z > best) { best = z; bi = f; bw[0] = w[0]; bw[1] = w[1]; bw[2] = w[2]; }
+                }
+                size_t pix = ((size_t)b * H + j) * W + i;
+                face_idx[pix] = bi;
+                for (int c = 0; c < C; ++c) {
+                    float v = 0.0f;
+                    if (bi >= 0) {
+                        const float *ff = fb + (size_t)bi * 3 * C;
+                        v = (bw[0] * ff[0 * C + c] + bw[1] * ff[1 * C + c]) + bw[2] * ff[2 * C + c];
+                    }
+                    out[pix * C + c] = v;
+                }
+            }
+        }
+    }
+    free(sxy);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* returns 0 ok, 1 = "depth map should be negative", 2 = "depth map should not be empty" */
+int orc_normalize_depth(const float *depth, int B, int HW, float *out)
+{
+    int any = 0;
+    for (size_t i = 0; i < (size_t)B * HW; ++i) {
+        if (depth[i] > 0.0f) return 1;
+        if (depth[i] != 0.0f) any = 1;
+    }
+    if (!any) return 2;
+    for (int b = 0; b < B; ++b) {
+        const float *d = depth + (size_t)b * HW;
+        float mn = INFINITY, mx = -INFINITY;
+        for (int i = 0; i < HW; ++i)
+            if (d[i] != 0.0f) { mn = fminf(mn, d[i]); mx = fmaxf(mx, d[i]); }
+        float range = mx - mn;
+        for (int i = 0; i < HW; ++i)
+            out[(size_t)b * HW + i] = (d[i] != 0.0f) ? (d[i] - mn) / range : d[i];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+static inline float src_index(float g, int size)
+{
+    float c = ((g + 1.0f) * (float)size - 1.0f) / 2.0f; /* align_corners = False */
+    c = fminf((float)(size - 1), fmaxf(c, 0.0f));        /* padding_mode = border */
+    return c;
+}
+
+/* tex: [Bt,C,T,T] with Bt in {1,B} (Bt==1 = the reference's stride-0 expand). mode 0 = bilinear,
+   1 = nearest. */
+void orc_texture_mapping(const float *uv, const float *tex, int B, int HW, int C, int T, int Bt,
+                         int mode, float *out)
+{
+    for (int b = 0; b < B; ++b) {
+        const float *tb = tex + (Bt == 1 ? 0 : (size_t)b * C * T * T);
+        for (int i = 0; i < HW; ++i) {
+            float u = uv[((size_t)b * HW + i) * 2 + 0], v = uv[((size_t)b * HW + i) * 2 + 1];
+            float gx = u * 2.0f - 1.0f;
+            float gy = (1.0f - v) * 2.0f - 1.0f;
+            float ix = src_index(gx, T), iy = src_index(gy, T);
+            float *o = out + ((size_t)b * HW + i) * C;
+            if (mode == 1) {
+                int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+                for (int c = 0; c < C; ++c)
+                    o[c] = (xn >= 0 && xn < T && yn >= 0 && yn < T) ? tb[((size_t)c * T + yn) * T + xn] : 0.0f;
+                continue;
+            }
+            float fx = floorf(ix), fy = floorf(iy);
+            int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+            float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+            float wne = (ix - (float)x0) * ((float)y1 - iy);
+            float wsw = ((float)x1 - ix) * (iy - (float)y0);
+            float wse = (ix - (float)x0) * (iy - (float)y0);
+            for (int c = 0; c < C; ++c) {
+                const float *tc = tb + (size_t)c * T * T;
+                float acc = 0.0f;
+                if (x0 >= 0 && x0 < T && y0 >= 0 && y0 < T) acc = acc + tc[(size_t)y0 * T + x0] * wnw;
+                if (x1 >= 0 && x1 < T && y0 >= 0 && y0 < T) acc = acc + tc[(size_t)y0 * T + x1] * wne;
+                if (x0 >= 0 && x0 < T && y1 >= 0 && y1 < T) acc = acc + tc[(size_t)y1 * T + x0] * wsw;
+                if (x1 >= 0 && x1 < T && y1 >= 0 && y1 < T) acc = acc + tc[(size_t)y1 * T + x1] * wse;
+                o[c] = acc;
+            }
+        }
+    }
+}
+
+/* grad_tex [C,T,T] += sum over all B views (expanded atlas: gradients of all copies add up,
+   src/models/textured_mesh.py:533-545 comment).  Sequential double accumulation: the GPU path
+   uses float atomics, compared with a tolerance. */
+void orc_texture_mapping_bwd(const float *grad_out, const float *uv, int B, int HW, int C, int T,
+                             float *grad_tex)
+{
+    double *acc = (double *)calloc((size_t)C * T * T, sizeof(double));
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < HW; ++i) {
+            float u = uv[((size_t)b * HW + i) * 2 + 0], v = uv[((size_t)b * HW + i) * 2 + 1];
+            float ix = src_index(u * 2.0f - 1.0f, T), iy = src_index((1.0f - v) * 2.0f - 1.0f, T);
+            float fx = floorf(ix), fy = floorf(iy);
+            int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+            float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+            float wne = (ix - (float)x0) * ((float)y1 - iy);
+            float wsw = ((float)x1 - ix) * (iy - (float)y0);
+            float wse = (ix - (float)x0) * (iy - (float)y0);
+            const float *g = grad_out + ((size_t)b * HW + i) * C;
+            for (int c = 0; c < C; ++c) {
+                double *tc = acc + (size_t)c * T * T;
+                if (x0 >= 0 && x0 < T && y0 >= 0 && y0 < T) tc[(size_t)y0 * T + x0] += (double)(g[c] * wnw);
+                if (x1 >= 0 && x1 < T && y0 >= 0 && y0 < T) tc[(size_t)y0 * T + x1] += (double)(g[c] * wne);
+                if (x0 >= 0 && x0 < T && y1 >= 0 && y1 < T) tc[(size_t)y1 * T + x0] += (double)(g[c] * wsw);
+                if (x1 >= 0 && x1 < T && y1 >= 0 && y1 < T) tc[(size_t)y1 * T + x1] += (double)(g[c] * wse);
+            }
+        }
+    for (size_t i = 0; i < (size_t)C * T * T; ++i) grad_tex[i] = (float)acc[i];
+    free(acc);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+void orc_gather_normals(const int64_t *face_idx, const float *fnorm, int B, int HW, int F, float *out)
+{
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < HW; ++i) {
+            int64_t f = face_idx[(size_t)b * HW + i];
+            if (f < 0) f += F; /* python negative index: -1 -> last face */
+            for (int c = 0; c < 3; ++c)
+                out[((size_t)b * HW + i) * 3 + c] = fnorm[((size_t)b * F + f) * 3 + c];
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* face_normals_z: [B,F] (= face_normals[view,2,face] of the reference's [B,3,F] tensor).
+   max_z[F]: per-face max over all pixels of all views showing the face; faces never seen keep
+   -inf here (torch-scatter leaves 0 there; the reference never reads those entries,
+   trainer.py:234).  mask[B,HW] u8: 1 = worthy or background. */
+void orc_view_weights(const int64_t *face_idx, const float *fnz, int B, int HW, int F,
+                      float *max_z, uint8_t *mask)
+{
+    for (int f = 0; f < F; ++f) max_z[f] = -INFINITY;
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < HW; ++i) {
+            int64_t f = face_idx[(size_t)b * HW + i];
+            if (f < 0) continue;
+            float z = fnz[(size_t)b * F + f];
+            if (z > max_z[f]) max_z[f] = z;
+        }
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < HW; ++i) {
+            int64_t f = face_idx[(size_t)b * HW + i];
+            uint8_t m = 1;
+            if (f >= 0) m = !(fnz[(size_t)b * F + f] < max_z[f]);
+            mask[(size_t)b * HW + i] = m;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* nerf-pytorch raw2outputs (raw_noise_std = 0).  raw [R,S,4], z_vals [R,S], rays_d [R,3].
+   outputs: rgb [R,3], disp [R], acc [R], weights [R,S], depth [R]. */
+void orc_raw2outputs(const float *raw, const float *z_vals, const float *rays_d, int R, int S,
+                     int white_bkgd, float *rgb, float *disp, float *acc, float *weights,
+                     float *depth)
+{
+    for (int r = 0; r < R; ++r) {
+        const float *d3 = rays_d + (size_t)r * 3;
+        float nrm = sqrtf((d3[0] * d3[0] + d3[1] * d3[1]) + d3[2] * d3[2]);
+        float T = 1.0f, c0 = 0, c1 = 0, c2 = 0, dep = 0, a = 0;
+        for (int s = 0; s < S; ++s) {
+            float dist = (s + 1 < S) ? (z_vals[(size_t)r * S + s + 1] - z_vals[(size_t)r * S + s]) : 1e10f;
+            dist = dist * nrm;
+            const float *q = raw + ((size_t)r * S + s) * 4;
+            float sigma = q[3] > 0.0f ? q[3] : 0.0f;
+            float alpha = 1.0f - expf(-sigma * dist);
+            float w = alpha * T;
+            T = T * ((1.0f - alpha) + 1e-10f);
+            weights[(size_t)r * S + s] = w;
+            c0 += w * (1.0f / (1.0f + expf(-q[0])));
+            c1 += w * (1.0f / (1.0f + expf(-q[1])));
+            c2 += w * (1.0f / (1.0f + expf(-q[2])));
+            dep += w * z_vals[(size_t)r * S + s];
+            a += w;
+        }
+        if (white_bkgd) { c0 += 1.0f - a; c1 += 1.0f - a; c2 += 1.0f - a; }
+        rgb[(size_t)r * 3 + 0] = c0; rgb[(size_t)r * 3 + 1] = c1; rgb[(size_t)r * 3 + 2] = c2;
+        depth[r] = dep; acc[r] = a;
+        float q = dep / a;
+        disp[r] = 1.0f / (q > 1e-10f ? q : 1e-10f); /* torch.max(1e-10, nan) -> nan */
+        if (q != q) disp[r] = q;
+    }
+}

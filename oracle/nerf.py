@@ -1,0 +1,101 @@
+"""ORACLE (test infrastructure) — numpy restatement of src/run_nerf_helpers.py.
+
+  embed          : run_nerf_helpers.py:15-65   (Embedder, get_embedder(multires); freq = 2**linspace(0,L-1,L), no pi)
+  nerf2d_forward : run_nerf_helpers.py:68-135  (NeRF2D; skip-cat AFTER layer `skips`, input first)
+  get_rays       : run_nerf_helpers.py:139-148
+  ndc_rays       : run_nerf_helpers.py:162-180
+  sample_pdf     : run_nerf_helpers.py:184-225
+Pinned by tests/golden/reference_vectors.npz (outputs of the reference's own functions)."""
+import numpy as np
+
+
+def embed(x, multires=10):
+    x = np.asarray(x, np.float32)
+    freqs = (2.0 ** np.linspace(0.0, multires - 1, multires)).astype(np.float32)
+    outs = [x]
+    for f in freqs:
+        outs.append(np.sin(x * f))
+        outs.append(np.cos(x * f))
+    return np.concatenate(outs, -1).astype(np.float32)
+
+
+def nerf2d_forward(e, weights, biases, out_w, out_b, skips=(4,), dtype=np.float32):
+    """weights[i]: [out,in] like nn.Linear; returns pre-activation outputs [N, output_ch]."""
+    e = np.asarray(e, dtype)
+    h = e
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        h = h @ np.asarray(w, dtype).T + np.asarray(b, dtype)
+        h = np.maximum(h, 0)
+        if i in skips:
+            h = np.concatenate([e, h], -1)
+    return h @ np.asarray(out_w, dtype).T + np.asarray(out_b, dtype)
+
+
+def texture_from_mlp(mlp_out, res):
+    """src/models/textured_mesh.py:298-301: (tanh+1)/2, [res*res,3] -> [1,3,res,res]."""
+    t = (np.tanh(mlp_out.astype(np.float32)) + 1) / 2
+    return t.reshape(1, res, res, 3).transpose(0, 3, 1, 2)
+
+
+def uv_grid(res):
+    """textured_mesh.py:269-273: meshgrid(linspace, linspace, indexing='xy') -> row i <-> v, col j <-> u."""
+    l = np.linspace(0, 1, res, dtype=np.float32)
+    u, v = np.meshgrid(l, l, indexing='xy')
+    return np.stack([u, v], -1).reshape(-1, 2)
+
+
+def get_rays(H, W, K, c2w):
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
+    dirs = np.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -np.ones_like(i)], -1)
+    c2w = np.asarray(c2w, np.float32)
+    rays_d = np.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = np.broadcast_to(c2w[:3, -1], rays_d.shape)
+    return rays_o.astype(np.float32), rays_d.astype(np.float32)
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2. * near / rays_o[..., 2]
+    return np.stack([o0, o1, o2], -1).astype(np.float32), np.stack([d0, d1, d2], -1).astype(np.float32)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
+    bins = np.asarray(bins, np.float32)
+    weights = np.asarray(weights, np.float32) + np.float32(1e-5)
+    pdf = weights / np.sum(weights, -1, keepdims=True)
+    cdf = np.cumsum(pdf, -1, dtype=np.float32)
+    cdf = np.concatenate([np.zeros_like(cdf[..., :1]), cdf], -1)
+    shape = list(cdf.shape[:-1]) + [N_samples]
+    if u is None:
+        if det:
+            u = np.broadcast_to(np.linspace(0., 1., N_samples, dtype=np.float32), shape)
+        else:
+            u = np.random.rand(*shape).astype(np.float32)
+        if pytest:
+            np.random.seed(0)
+            if det:
+                u = np.broadcast_to(np.linspace(0., 1., N_samples), shape).astype(np.float32)
+            else:
+                u = np.random.rand(*shape).astype(np.float32)
+    u = np.ascontiguousarray(u, np.float32)
+    out = np.empty(shape, np.float32)
+    nb = cdf.shape[-1]
+    flat_c = cdf.reshape(-1, nb); flat_b = bins.reshape(-1, nb); flat_u = u.reshape(-1, N_samples)
+    flat_o = out.reshape(-1, N_samples)
+    for r in range(flat_c.shape[0]):
+        inds = np.searchsorted(flat_c[r], flat_u[r], side='right')
+        below = np.maximum(0, inds - 1)
+        above = np.minimum(nb - 1, inds)
+        c0, c1 = flat_c[r][below], flat_c[r][above]
+        b0, b1 = flat_b[r][below], flat_b[r][above]
+        denom = c1 - c0
+        denom = np.where(denom < 1e-5, np.float32(1.0), denom)
+        t = (flat_u[r] - c0) / denom
+        flat_o[r] = b0 + t * (b1 - b0)
+    return out

@@ -1,0 +1,292 @@
+"""ORACLE (test infrastructure) — plain-PyTorch fp32 restatement of the SD2-depth
+`UNet2DConditionModel` that the reference calls at src/stable_diffusion_depth.py:422-423
+(`self.unet(x[2,5,h,w], t, encoder_hidden_states=ctx[2,77,1024])['sample']`).
+
+The module graph and parameter names follow diffusers 0.27.2 (requirements.txt:13) and the
+`stabilityai/stable-diffusion-2-depth/unet/config.json` hyper-parameters listed in SURVEY.md
+Appendix A.5.  diffusers and the weights are NOT available offline, and the reference holds no
+test vectors for this stage => PARITY UNPINNED against diffusers; the HIP engine is compared with
+this module on seeded random-init weights (which is also what BASELINE.json prescribes).
+"""
+import math
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+SD2_DEPTH = dict(in_channels=5, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                 down_attn=(True, True, True, False), up_attn=(False, True, True, True),
+                 cross_attention_dim=1024, heads=(5, 10, 20, 20), groups=32, norm_eps=1e-5)
+
+
+def tiny_config(ch=(64, 128), heads=(1, 2), ctx_dim=64, in_channels=5, groups=32):
+    """A shrunken config (same topology rules) for fast CPU/GPU parity tests."""
+    n = len(ch)
+    return dict(in_channels=in_channels, out_channels=4, block_out_channels=tuple(ch), layers_per_block=2,
+                down_attn=tuple([True] * (n - 1) + [False]), up_attn=tuple([False] + [True] * (n - 1)),
+                cross_attention_dim=ctx_dim, heads=tuple(heads), groups=groups, norm_eps=1e-5)
+
+
+def timestep_embedding(t, dim):
+    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0)."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
+    emb = t.float()[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(cin, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb, groups, eps):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x, temb):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class Attention(nn.Module):
+    def __init__(self, qdim, kvdim, heads):
+        super().__init__()
+        self.heads = heads
+        self.to_q = nn.Linear(qdim, qdim, bias=False)
+        self.to_k = nn.Linear(kvdim, qdim, bias=False)
+        self.to_v = nn.Linear(kvdim, qdim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(qdim, qdim)])
+
+    def forward(self, x, ctx=None):
+        ctx = x if ctx is None else ctx
+        B, S, C = x.shape
+        H = self.heads
+        q = self.to_q(x).view(B, S, H, C // H).transpose(1, 2)
+        k = self.to_k(ctx).view(B, -1, H, C // H).transpose(1, 2)
+        v = self.to_v(ctx).view(B, -1, H, C // H).transpose(1, 2)
+        a = torch.softmax((q @ k.transpose(-1, -2)) * (C // H) ** -0.5, dim=-1) @ v
+        return self.to_out[0](a.transpose(1, 2).reshape(B, S, C))
+
+
+class GEGLU(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.proj = nn.Linear(cin, cout * 2)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Identity(), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, ctx_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, dim, heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, ctx_dim, heads)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, ctx):
+        x = x + self.attn1(self.norm1(x))
+        x = x + self.attn2(self.norm2(x), ctx)
+        return x + self.ff(self.norm3(x))
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, dim, heads, ctx_dim, groups):
+        super().__init__()
+        self.norm = nn.GroupNorm(groups, dim, eps=1e-6)
+        self.proj_in = nn.Linear(dim, dim)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, heads, ctx_dim)])
+        self.proj_out = nn.Linear(dim, dim)
+
+    def forward(self, x, ctx):
+        B, C, H, W = x.shape
+        h = self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        h = self.proj_in(h)
+        for blk in self.transformer_blocks:
+            h = blk(h, ctx)
+        h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        return h + x
+
+
+class Sampler(nn.Module):
+    def __init__(self, c, stride):
+        super().__init__()
+        self.stride = stride
+        self.conv = nn.Conv2d(c, c, 3, stride=stride, padding=1)
+
+    def forward(self, x):
+        if self.stride == 1:
+            x = F.interpolate(x, scale_factor=2.0, mode='nearest')
+        return self.conv(x)
+
+
+class Block(nn.Module):
+    pass
+
+
+class UNet2DConditionModelRef(nn.Module):
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = dict(SD2_DEPTH if cfg is None else cfg)
+        self.cfg = cfg
+        ch = cfg['block_out_channels']
+        g, eps, cd = cfg['groups'], cfg['norm_eps'], cfg['cross_attention_dim']
+        temb = ch[0] * 4
+        self.in_channels = cfg['in_channels']
+        self.conv_in = nn.Conv2d(cfg['in_channels'], ch[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch[0], temb)
+        self.down_blocks = nn.ModuleList()
+        out = ch[0]
+        for i, c in enumerate(ch):
+            blk = Block()
+            cin, out = out, c
+            blk.resnets = nn.ModuleList([ResnetBlock2D(cin if j == 0 else out, out, temb, g, eps)
+                                         for j in range(cfg['layers_per_block'])])
+            if cfg['down_attn'][i]:
+                blk.attentions = nn.ModuleList([Transformer2DModel(out, cfg['heads'][i], cd, g)
+                                                for _ in range(cfg['layers_per_block'])])
+            if i != len(ch) - 1:
+                blk.downsamplers = nn.ModuleList([Sampler(out, 2)])
+            self.down_blocks.append(blk)
+        self.mid_block = Block()
+        self.mid_block.resnets = nn.ModuleList([ResnetBlock2D(ch[-1], ch[-1], temb, g, eps) for _ in range(2)])
+        self.mid_block.attentions = nn.ModuleList([Transformer2DModel(ch[-1], cfg['heads'][-1], cd, g)])
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(ch)); rheads = list(reversed(cfg['heads']))
+        out = rev[0]
+        for i, c in enumerate(rev):
+            blk = Block()
+            prev, out = out, c
+            inp = rev[min(i + 1, len(ch) - 1)]
+            n = cfg['layers_per_block'] + 1
+            blk.resnets = nn.ModuleList()
+            for j in range(n):
+                skip = inp if j == n - 1 else out
+                rin = prev if j == 0 else out
+                blk.resnets.append(ResnetBlock2D(rin + skip, out, temb, g, eps))
+            if cfg['up_attn'][i]:
+                blk.attentions = nn.ModuleList([Transformer2DModel(out, rheads[i], cd, g) for _ in range(n)])
+            if i != len(ch) - 1:
+                blk.upsamplers = nn.ModuleList([Sampler(out, 1)])
+            self.up_blocks.append(blk)
+        self.conv_norm_out = nn.GroupNorm(g, ch[0], eps=eps)
+        self.conv_out = nn.Conv2d(ch[0], cfg['out_channels'], 3, padding=1)
+
+    def forward(self, sample, timestep, encoder_hidden_states):
+        t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(sample.shape[0])
+        temb = self.time_embedding(timestep_embedding(t, self.cfg['block_out_channels'][0]))
+        ctx = encoder_hidden_states
+        h = self.conv_in(sample)
+        skips = [h]
+        for blk in self.down_blocks:
+            for j, r in enumerate(blk.resnets):
+                h = r(h, temb)
+                if hasattr(blk, 'attentions'):
+                    h = blk.attentions[j](h, ctx)
+                skips.append(h)
+            if hasattr(blk, 'downsamplers'):
+                h = blk.downsamplers[0](h)
+                skips.append(h)
+        h = self.mid_block.resnets[0](h, temb)
+        h = self.mid_block.attentions[0](h, ctx)
+        h = self.mid_block.resnets[1](h, temb)
+        for blk in self.up_blocks:
+            for j, r in enumerate(blk.resnets):
+                h = r(torch.cat([h, skips.pop()], dim=1), temb)
+                if hasattr(blk, 'attentions'):
+                    h = blk.attentions[j](h, ctx)
+            if hasattr(blk, 'upsamplers'):
+                h = blk.upsamplers[0](h)
+        h = self.conv_out(F.silu(self.conv_norm_out(h)))
+        return {'sample': h}
+
+
+def randomize_affine(model, seed=0, scale=0.1):
+    """Perturb norm affine parameters (default init is weight=1, bias=0, which hides bugs)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, (nn.GroupNorm, nn.LayerNorm)):
+                m.weight.add_(scale * torch.randn(m.weight.shape, generator=g))
+                m.bias.add_(scale * torch.randn(m.bias.shape, generator=g))
+    return model
+
+
+def count_flops(cfg, h, w, ctx_len=77):
+    """2*MACs of all conv/linear/attention matmuls for ONE sample (SURVEY §8d definition)."""
+    ch = cfg['block_out_channels']; cd = cfg['cross_attention_dim']; temb = ch[0] * 4
+    fl = {'conv': 0, 'proj': 0, 'attn': 0, 'ff': 0}
+
+    def conv(cin, cout, hh, ww, k=3):
+        fl['conv'] += 2 * hh * ww * cin * cout * k * k
+
+    def res(cin, cout, hh, ww):
+        conv(cin, cout, hh, ww); conv(cout, cout, hh, ww)
+        fl['proj'] += 2 * temb * cout
+        if cin != cout:
+            conv(cin, cout, hh, ww, 1)
+
+    def tr(c, hh, ww):
+        s = hh * ww
+        fl['proj'] += 2 * s * c * c * 2            # proj_in/out
+        fl['proj'] += 2 * s * c * c * 4            # attn1 q,k,v,out
+        fl['proj'] += 2 * s * c * c * 2 + 2 * ctx_len * cd * c * 2   # attn2 q,out + k,v
+        fl['attn'] += 4 * s * s * c + 4 * s * ctx_len * c
+        fl['ff'] += 2 * s * c * 8 * c + 2 * s * 4 * c * c
+
+    fl['proj'] += 2 * (ch[0] * temb + temb * temb)
+    conv(cfg['in_channels'], ch[0], h, w)
+    hh, ww, out = h, w, ch[0]
+    for i, c in enumerate(ch):
+        cin, out = out, c
+        for j in range(cfg['layers_per_block']):
+            res(cin if j == 0 else out, out, hh, ww)
+            if cfg['down_attn'][i]:
+                tr(out, hh, ww)
+        if i != len(ch) - 1:
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+            conv(out, out, hh, ww)
+    res(ch[-1], ch[-1], hh, ww); tr(ch[-1], hh, ww); res(ch[-1], ch[-1], hh, ww)
+    rev = list(reversed(ch)); out = rev[0]
+    for i, c in enumerate(rev):
+        prev, out = out, c
+        inp = rev[min(i + 1, len(ch) - 1)]
+        n = cfg['layers_per_block'] + 1
+        for j in range(n):
+            res((prev if j == 0 else out) + (inp if j == n - 1 else out), out, hh, ww)
+            if cfg['up_attn'][i]:
+                tr(out, hh, ww)
+        if i != len(ch) - 1:
+            hh, ww = hh * 2, ww * 2
+            conv(out, out, hh, ww)
+    conv(ch[0], cfg['out_channels'], hh, ww)
+    fl['total'] = sum(fl.values())
+    return fl

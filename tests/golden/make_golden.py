@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the importable pieces of the reference.
+
+Runs ONLY in the build container (needs /root/reference); the GPU box uses the committed
+.npz/.json outputs in this directory.  Nothing from the reference's source text is stored:
+only seeded inputs and the outputs its functions returned here.
+
+Pieces exercised (reference file:line):
+  src/run_nerf_helpers.py:15-65   Embedder / get_embedder
+  src/run_nerf_helpers.py:68-135  NeRF2D
+  src/run_nerf_helpers.py:139-225 get_rays / ndc_rays / sample_pdf
+  src/training/trainer.py:155-249 create_face_view_map / compare_face_normals_between_views
+  src/training/trainer.py:38-106  scale helpers / DreamTimeScheduler
+  src/utils.py                    get_nonzero_region_tuple, grid split/merge, get_view_direction
+  src/training/views_dataset.py   Zero123PlusDataset / MultiviewDataset pose lists
+  src/models/render.py:48-74      normalize_multiple_depth
+  src/models/mesh.py:27-65        calculate_face_normals / normalize_mesh
+  src/configs/train_config.py     dataclass defaults
+Third-party stand-ins follow SURVEY.md Appendix C (stubs for absent packages; scatter_max by
+scatter_reduce('amax'), exact because max is order-free).
+"""
+import sys, types, importlib, importlib.util, json, os, dataclasses
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _stub_env():
+    import PIL, einops, tqdm, transformers  # noqa: F401  real packages first
+    from transformers import CLIPTextModel, CLIPTokenizer, logging  # noqa: F401
+
+    class _Any:
+        def __init__(s, *a, **k): pass
+        def __call__(s, *a, **k): return _Any()
+        def __getattr__(s, k):
+            if k.startswith('__'):
+                raise AttributeError(k)
+            return _Any()
+
+    def stub(name):
+        m = types.ModuleType(name); m.__file__ = '<stub>'; m.__path__ = []
+        def _ga(k):
+            if k.startswith('__'):
+                raise AttributeError(k)
+            return _Any()
+        m.__getattr__ = _ga
+        sys.modules[name] = m
+        return m
+    for n in ['loguru', 'torchvision', 'torchvision.transforms', 'cv2', 'imageio', 'pyrallis',
+              'torch_scatter', 'diffusers', 'kaolin', 'wandb', 'omegaconf', 'xatlas', 'matplotlib',
+              'matplotlib.pyplot']:
+        if n not in sys.modules:
+            try:
+                importlib.import_module(n)
+            except Exception:
+                stub(n)
+    sys.modules['torch_scatter'].scatter_max = lambda src, index, dim=0: (
+        torch.full((int(index.max()) + 1,), float('-inf'), dtype=src.dtype).scatter_reduce(0, index, src, 'amax'), None)
+    sys.path.insert(0, REF)
+
+
+def main():
+    out = {}
+    meta = {}
+    # ---- run_nerf_helpers (no stubs needed) --------------------------------------------
+    spec = importlib.util.spec_from_file_location("ref_rnh", os.path.join(REF, "src/run_nerf_helpers.py"))
+    rnh = importlib.util.module_from_spec(spec); spec.loader.exec_module(rnh)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(96, 2, generator=g)
+    embed, odim = rnh.get_embedder(10)
+    out['embed_x'] = x.numpy(); out['embed_y'] = embed(x).numpy(); meta['embed_out_dim'] = odim
+
+    torch.manual_seed(1234)
+    net = rnh.NeRF2D(D=8, W=256, input_ch=42, output_ch=3, skips=[4])
+    meta['nerf2d_params'] = sum(p.numel() for p in net.parameters())
+    meta['nerf2d_keys'] = list(net.state_dict().keys())
+    e = embed(x)
+    e.requires_grad_(False)
+    y = net(e)
+    out['nerf2d_seed1234_y'] = y.detach().numpy()
+    loss = (y * torch.linspace(-1, 1, y.numel()).reshape(y.shape)).sum()
+    loss.backward()
+    out['nerf2d_seed1234_gw0'] = net.pts_linears[0].weight.grad.numpy()
+    out['nerf2d_seed1234_gb_out'] = net.output_linear.bias.grad.numpy()
+    out['nerf2d_seed1234_gw5_sum'] = np.array(net.pts_linears[5].weight.grad.double().sum().item())
+    # small net with stored weights (independent of torch RNG stream)
+    torch.manual_seed(7)
+    small = rnh.NeRF2D(D=8, W=64, input_ch=42, output_ch=3, skips=[4])
+    for k, v in small.state_dict().items():
+        out['small_' + k] = v.numpy()
+    out['small_y'] = small(e).detach().numpy()
+
+    # rays
+    H, W = 6, 8
+    f = 5.0
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=np.float32)
+    c2w = torch.tensor([[0.8, -0.36, 0.48, 0.3], [0.6, 0.48, -0.64, -0.2], [0.0, 0.8, 0.6, 1.7]], dtype=torch.float32)
+    ro, rd = rnh.get_rays(H, W, K, c2w)
+    out['rays_K'] = K; out['rays_c2w'] = c2w.numpy(); out['rays_o'] = ro.numpy(); out['rays_d'] = rd.numpy()
+    ro2, rd2 = rnh.get_rays_np(H, W, K, c2w.numpy())
+    out['rays_o_np'] = np.ascontiguousarray(ro2); out['rays_d_np'] = rd2
+    no, nd = rnh.ndc_rays(H, W, f, 1.0, ro, rd)
+    out['ndc_o'] = no.numpy(); out['ndc_d'] = nd.numpy()
+    g = torch.Generator().manual_seed(5)
+    bins = torch.sort(torch.rand(7, 17, generator=g) * 4 + 2, -1).values
+    wts = torch.rand(7, 16, generator=g)
+    out['pdf_bins'] = bins.numpy(); out['pdf_w'] = wts.numpy()
+    out['pdf_det'] = rnh.sample_pdf(bins, wts, 24, det=True).numpy()
+    out['pdf_pytest'] = rnh.sample_pdf(bins, wts, 24, det=False, pytest=True).numpy()
+    out['pdf_det_pytest'] = rnh.sample_pdf(bins, wts, 24, det=True, pytest=True).numpy()
+
+    # ---- stubbed imports ----------------------------------------------------------------
+    _stub_env()
+    T = importlib.import_module('src.training.trainer')
+    U = importlib.import_module('src.utils')
+    VD = importlib.import_module('src.training.views_dataset')
+    CFG = importlib.import_module('src.configs.train_config')
+    R = importlib.import_module('src.models.render')
+    M = importlib.import_module('src.models.mesh')
+
+    g = torch.Generator().manual_seed(3)
+    B, Hh, Ww, F = 3, 20, 24, 17
+    face_idx = torch.randint(-1, F, (B, 1, Hh, Ww), generator=g)
+    face_idx[:, :, :3] = -1
+    fn = torch.randn(B, 3, F, generator=g)
+    fn[1, 2, 4] = fn[0, 2, 4]  # an exact tie between two views
+    fvm = T.ConTEXTure.create_face_view_map(None, face_idx)
+    masks = T.ConTEXTure.compare_face_normals_between_views(None, fvm, fn, face_idx)
+    out['vw_face_idx'] = face_idx.numpy(); out['vw_face_normals'] = fn.numpy()
+    out['vw_face_view_map'] = fvm.numpy(); out['vw_masks'] = masks.numpy()
+    toy = torch.tensor([[[[0, -1], [1, 1]]], [[[1, 0], [-1, 2]]]])
+    out['vw_toy_map'] = T.ConTEXTure.create_face_view_map(None, toy).numpy()
+
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    ac = torch.cumprod(1.0 - betas, 0)
+    ds = T.DreamTimeScheduler(ac, 5000, m=500, s=125)
+    ii = [0, 1, 2, 10, 100, 1000, 2500, 4000, 4998, 4999]
+    out['dreamtime_i'] = np.array(ii); out['dreamtime_t'] = np.array([int(ds.get_t(i)) for i in ii])
+    z = torch.linspace(-2, 2, 9)
+    out['scale_in'] = z.numpy()
+    out['scale_latents'] = T.scale_latents(z).numpy(); out['unscale_latents'] = T.unscale_latents(z).numpy()
+    out['scale_image'] = T.scale_image(z).numpy(); out['unscale_image'] = T.unscale_image(z).numpy()
+
+    # utils
+    boxes = []
+    masks_spec = [(1200, 1200, 300, 900, 400, 700), (1200, 1200, 0, 1200, 10, 20), (64, 96, 5, 9, 80, 96),
+                  (512, 512, 100, 101, 200, 201), (37, 53, 3, 30, 1, 50)]
+    for (h, w, y0, y1, x0, x1) in masks_spec:
+        m = torch.zeros(h, w); m[y0:y1, x0:x1] = 1
+        boxes.append([int(v) for v in U.get_nonzero_region_tuple(m)])
+    meta['crop_specs'] = masks_spec; meta['crop_boxes'] = boxes
+    grid = torch.arange(1 * 4 * 120 * 80, dtype=torch.float32).reshape(1, 4, 120, 80)
+    tiles = U.split_3x2_grid_to_tensor_with_6_elements(grid, 40)
+    out['grid_tiles_sum'] = tiles.reshape(6, -1).sum(1).numpy()
+    out['grid_tiles_corner'] = tiles[:, 0, 0, 0].numpy()
+    meta['grid_roundtrip'] = bool(torch.equal(U.merge_tensor_with_6_elements_to_3x2_grid(tiles, 40), grid)) \
+        if hasattr(U, 'merge_tensor_with_6_elements_to_3x2_grid') else None
+    th = torch.tensor([0.1, 1.0, 1.0, 1.0, 1.0, 2.9, 1.0]); ph = torch.tensor([0.0, 0.2, 1.6, 3.1, 4.7, 1.0, 6.2])
+    out['viewdir_theta'] = th.numpy(); out['viewdir_phi'] = ph.numpy()
+    out['viewdir'] = U.get_view_direction(th, ph, np.deg2rad(40.0), np.deg2rad(70.0)).numpy()
+
+    # view datasets
+    rc = CFG.RenderConfig()
+    for name, cls in [('zero123plus', VD.Zero123PlusDataset), ('multiview', VD.MultiviewDataset)]:
+        dsx = cls(rc, 'cpu')
+        rows = []
+        for i in range(dsx.size):
+            d = dsx.collate([i])
+            rows.append({'dir': int(d['dir'][0]), 'theta': float(d['theta']), 'phi': float(d['phi']),
+                         'radius': float(d['radius']), 'base_theta': float(d.get('base_theta', 0.0))})
+        meta['views_' + name] = rows
+
+    # config defaults
+    def dflt(cls):
+        o = {}
+        for fld in dataclasses.fields(cls):
+            if fld.default is not dataclasses.MISSING:
+                v = fld.default
+            elif fld.default_factory is not dataclasses.MISSING:
+                try:
+                    v = fld.default_factory()
+                except Exception:
+                    v = '<required>'
+            else:
+                v = '<required>'
+            o[fld.name] = str(v) if not isinstance(v, (int, float, bool, str, list, type(None))) else v
+        return o
+    meta['cfg_render'] = dflt(CFG.RenderConfig); meta['cfg_guide'] = dflt(CFG.GuideConfig)
+    meta['cfg_optim'] = dflt(CFG.OptimConfig); meta['cfg_log'] = dflt(CFG.LogConfig)
+
+    # normalize_multiple_depth (pure torch in Renderer) and Mesh helpers
+    g = torch.Generator().manual_seed(9)
+    d = -(torch.rand(2, 12, 10, 1, generator=g) + 0.5)
+    d[:, :4] = 0
+    d[0, 7, 3, 0] = 0
+    out['depth_raw'] = d.numpy()
+    out['depth_norm'] = R.Renderer.normalize_multiple_depth(None, d).numpy()
+    v = torch.randn(30, 3, generator=g) * torch.tensor([1.0, 2.0, 0.5]) + 0.3
+    fc = torch.randint(0, 30, (40, 3), generator=g)
+    fc[:, 1] = (fc[:, 0] + 1 + fc[:, 1] % 28) % 30
+    fc[:, 2] = (fc[:, 0] + 29) % 30
+    n, a = M.Mesh.calculate_face_normals(v, fc)
+    out['mesh_v'] = v.numpy(); out['mesh_f'] = fc.numpy(); out['mesh_fn'] = n.numpy(); out['mesh_area'] = a.numpy()
+    ms = types.SimpleNamespace(vertices=v.clone())
+    out['mesh_v_norm'] = M.Mesh.normalize_mesh(ms, inplace=True, target_scale=0.6, dy=0.25).vertices.numpy()
+
+    np.savez_compressed(os.path.join(HERE, 'reference_vectors.npz'), **out)
+    with open(os.path.join(HERE, 'reference_meta.json'), 'w') as fjs:
+        json.dump(meta, fjs, indent=1)
+    print('wrote', len(out), 'arrays;', os.path.getsize(os.path.join(HERE, 'reference_vectors.npz')), 'bytes')
+
+
+if __name__ == '__main__':
+    main()
