@@ -1,0 +1,760 @@
+// Raster / UV / view-weight kernels for gfx950.  HBM-bound integer+float32 work: no MFMA here.
+// Compiled with -ffp-contract=off: every float op below is one IEEE binary32 op in source order,
+// mirroring oracle/geometry_ref.c so face indices AND interpolated floats compare bit-exactly.
+//
+// Reference call sites replaced (see include/ctx_nerf.h for the per-entry citations):
+//   src/models/render.py:112-157, src/models/textured_mesh.py:167-190, src/training/trainer.py:155-249
+#include "common.h"
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------
+// prepare_vertices: two tiny kernels (vertex transform, then per-face gather + normal).
+__global__ void k_vertex_transform(const float *__restrict__ verts, const float *__restrict__ cam,
+                                   const float *__restrict__ proj3, int V, float *__restrict__ vc,
+                                   float *__restrict__ vi)
+{
+    int b = blockIdx.y;
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float *M = cam + (size_t)b * 12;
+    const float *p = verts + ((size_t)b * V + v) * 3;
+    float x = p[0], y = p[1], z = p[2];
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float acc = x * M[0 * 3 + k];
+        acc = acc + y * M[1 * 3 + k];
+        acc = acc + z * M[2 * 3 + k];
+        acc = acc + M[3 * 3 + k];
+        o[k] = acc;
+    }
+    float *q = vc + ((size_t)b * V + v) * 3;
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+    float px = o[0] * proj3[0], py = o[1] * proj3[1], pz = o[2] * proj3[2];
+    vi[((size_t)b * V + v) * 2 + 0] = px / pz;
+    vi[((size_t)b * V + v) * 2 + 1] = py / pz;
+}
+
+__global__ void k_face_gather(const float *__restrict__ vc, const float *__restrict__ vi,
+                              const int64_t *__restrict__ faces, int V, int F,
+                              float *__restrict__ fv_cam, float *__restrict__ fv_img,
+                              float *__restrict__ fnorm)
+{
+    int b = blockIdx.y;
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float p[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int64_t vid = faces[(size_t)f * 3 + k];
+        const float *s = vc + ((size_t)b * V + vid) * 3;
+        p[k][0] = s[0]; p[k][1] = s[1]; p[k][2] = s[2];
+        float *d = fv_cam + (((size_t)b * F + f) * 3 + k) * 3;
+        d[0] = p[k][0]; d[1] = p[k][1]; d[2] = p[k][2];
+        const float *si = vi + ((size_t)b * V + vid) * 2;
+        float *di = fv_img + (((size_t)b * F + f) * 3 + k) * 2;
+        di[0] = si[0]; di[1] = si[1];
+    }
+    float e0x = p[1][0] - p[0][0], e0y = p[1][1] - p[0][1], e0z = p[1][2] - p[0][2];
+    float e1x = p[2][0] - p[0][0], e1y = p[2][1] - p[0][1], e1z = p[2][2] - p[0][2];
+    float nx = e0y * e1z - e0z * e1y;
+    float ny = e0z * e1x - e0x * e1z;
+    float nz = e0x * e1y - e0y * e1x;
+    float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+    float d = len + 1e-10f;
+    float *o = fnorm + ((size_t)b * F + f) * 3;
+    o[0] = nx / d; o[1] = ny / d; o[2] = nz / d;
+}
+
+extern "C" int32_t ctx_prepare_vertices(const float *verts, const int64_t *faces, const float *cam,
+                                        const float *proj3, int32_t B, int32_t V, int32_t F,
+                                        float *fv_cam, float *fv_img, float *fnorm, void *ws,
+                                        ctx_stream_t stream)
+{
+    CTX_REQUIRE(verts && faces && cam && proj3 && fv_cam && fv_img && fnorm && ws, "prepare_vertices: null pointer");
+    CTX_REQUIRE(B > 0 && V > 0 && F > 0, "prepare_vertices: bad sizes B=%d V=%d F=%d", B, V, F);
+    hipStream_t s = (hipStream_t)stream;
+    float *vc = (float *)ws;
+    float *vi = vc + (size_t)B * V * 3;
+    hipLaunchKernelGGL(k_vertex_transform, dim3(cdiv(V, 256), B), dim3(256), 0, s, verts, cam, proj3, V, vc, vi);
+    hipLaunchKernelGGL(k_face_gather, dim3(cdiv(F, 256), B), dim3(256), 0, s, vc, vi, faces, V, F, fv_cam, fv_img, fnorm);
+    CTX_CHECK_LAUNCH("prepare_vertices");
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rasteriser.  Two kernels:
+//   k_raster_bin : one workgroup per 64x64-pixel coarse tile scans all F faces (bbox vs tile) and
+//                  appends surviving face ids to a per-tile list in the workspace.
+//   k_raster     : one workgroup per 32x8 fine tile (one pixel per lane, 256 B of int64 indices per
+//                  row) culls its coarse list to an LDS record list, then every pixel walks the
+//                  LDS list.  Winner = max z, ties -> lowest face id (== "first face wins under a
+//                  strict >" of the brute-force order), so list order is irrelevant.
+#define COARSE 64
+#define FT_W 32
+#define FT_H 8
+
+struct FaceRec {   // 64 B
+    float ax, ay, bx, by, cx, cy;
+    float z0, z1, z2;
+    float xmin, xmax, ymin, ymax;
+    int id;
+    int pad0, pad1;
+};
+
+__device__ __forceinline__ void load_face(const float *__restrict__ fxy, const float *__restrict__ fz,
+                                          int zstride, float mult, FaceRec &r)
+{
+    r.ax = fxy[0] * mult; r.ay = fxy[1] * mult; r.bx = fxy[2] * mult;
+    r.by = fxy[3] * mult; r.cx = fxy[4] * mult; r.cy = fxy[5] * mult;
+    r.z0 = fz[0]; r.z1 = fz[zstride]; r.z2 = fz[2 * zstride];
+    r.xmin = fminf(fminf(r.ax, r.bx), r.cx); r.xmax = fmaxf(fmaxf(r.ax, r.bx), r.cx);
+    r.ymin = fminf(fminf(r.ay, r.by), r.cy); r.ymax = fmaxf(fmaxf(r.ay, r.by), r.cy);
+}
+
+__device__ __forceinline__ float pix_x(int i, int W, float mult) { return (mult / (float)W) * (float)(2 * i + 1 - W); }
+__device__ __forceinline__ float pix_y(int j, int H, float mult) { return (mult / (float)H) * (float)(H - 2 * j - 1); }
+
+// rect of pixels [i0,i1] x [j0,j1] (inclusive) can contain a covered pixel only if this is true
+__device__ __forceinline__ bool rect_overlap(const FaceRec &r, float xlo, float xhi, float ylo, float yhi)
+{
+    return !(xhi < r.xmin || xlo >= r.xmax || yhi < r.ymin || ylo >= r.ymax);
+}
+
+__global__ __launch_bounds__(256) void k_raster_bin(int H, int W, const float *__restrict__ fz, int zstride,
+                                                    const float *__restrict__ fxy, int F, float mult,
+                                                    int ntx, int nty, int *__restrict__ lists,
+                                                    int *__restrict__ counts)
+{
+    int b = blockIdx.y;
+    int tile = blockIdx.x;
+    int tx = tile % ntx, ty = tile / ntx;
+    int i0 = tx * COARSE, i1 = min(W, i0 + COARSE) - 1;
+    int j0 = ty * COARSE, j1 = min(H, j0 + COARSE) - 1;
+    float xlo = pix_x(i0, W, mult), xhi = pix_x(i1, W, mult);
+    float yhi = pix_y(j0, H, mult), ylo = pix_y(j1, H, mult);
+    __shared__ int s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    int *list = lists + ((size_t)b * ntx * nty + tile) * F;
+    const float *xyb = fxy + (size_t)b * F * 6;
+    const float *zb = fz + (size_t)b * F * 3 * zstride;
+    for (int f0 = 0; f0 < F; f0 += 256) {
+        int f = f0 + threadIdx.x;
+        bool keep = false;
+        if (f < F) {
+            FaceRec r;
+            load_face(xyb + (size_t)f * 6, zb + (size_t)f * 3 * zstride, zstride, mult, r);
+            keep = rect_overlap(r, xlo, xhi, ylo, yhi);
+        }
+        unsigned long long m = __ballot(keep);
+        int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_count, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (keep) list[base + __popcll(m & ((1ull << lane) - 1))] = f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[(size_t)b * ntx * nty + tile] = s_count;
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_raster(int H, int W, const float *__restrict__ fz, int zstride,
+                                                const float *__restrict__ fxy, const float *__restrict__ feat,
+                                                int featB, int C, const float *__restrict__ fnorm, int F,
+                                                float mult, float eps, int ntx, int nty,
+                                                const int *__restrict__ lists, const int *__restrict__ counts,
+                                                float *__restrict__ out, float *__restrict__ out_uv,
+                                                int64_t *__restrict__ face_idx, float *__restrict__ normals)
+{
+    __shared__ FaceRec s_rec[256];
+    __shared__ int s_n;
+    int b = blockIdx.z;
+    int fi0 = blockIdx.x * FT_W, fj0 = blockIdx.y * FT_H;
+    int lx = threadIdx.x % FT_W, ly = threadIdx.x / FT_W;
+    int i = fi0 + lx, j = fj0 + ly;
+    bool active = (i < W) && (j < H);
+    int fi1 = min(W, fi0 + FT_W) - 1, fj1 = min(H, fj0 + FT_H) - 1;
+    float txlo = pix_x(fi0, W, mult), txhi = pix_x(fi1, W, mult);
+    float tyhi = pix_y(fj0, H, mult), tylo = pix_y(fj1, H, mult);
+    float x0 = pix_x(i, W, mult), y0 = pix_y(j, H, mult);
+    int ctile = (fj0 / COARSE) * ntx + (fi0 / COARSE);
+    const int *list = lists + ((size_t)b * ntx * nty + ctile) * F;
+    int n = counts[(size_t)b * ntx * nty + ctile];
+    const float *xyb = fxy + (size_t)b * F * 6;
+    const float *zb = fz + (size_t)b * F * 3 * zstride;
+
+    float best = -INFINITY, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
+    int bi = -1;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        int k = c0 + threadIdx.x;
+        if (k < n) {
+            int f = list[k];
+            FaceRec r;
+            load_face(xyb + (size_t)f * 6, zb + (size_t)f * 3 * zstride, zstride, mult, r);
+            if (rect_overlap(r, txlo, txhi, tylo, tyhi)) {
+                r.id = f;
+                int slot = atomicAdd(&s_n, 1);
+                s_rec[slot] = r;
+            }
+        }
+        __syncthreads();
+        int m = s_n;
+        if (active) {
+            for (int q = 0; q < m; ++q) {
+                const FaceRec &r = s_rec[q];
+                if (x0 < r.xmin || x0 >= r.xmax || y0 < r.ymin || y0 >= r.ymax) continue;
+                float mm = r.bx - r.ax, p = r.by - r.ay, nn = r.cx - r.ax, qq = r.cy - r.ay;
+                float s = x0 - r.ax, t = y0 - r.ay;
+                float k1 = s * qq - nn * t;
+                float k2 = mm * t - s * p;
+                float k3 = mm * qq - nn * p;
+                float den = k3 + eps;
+                float w1 = k1 / den;
+                float w2 = k2 / den;
+                float w0 = (1.0f - w1) - w2;
+                if (w0 < 0.0f || w1 < 0.0f || w2 < 0.0f) continue;
+                float z = (w0 * r.z0 + w1 * r.z1) + w2 * r.z2;
+                if (z > best || (z == best && r.id < bi)) {
+                    best = z; bi = r.id; bw0 = w0; bw1 = w1; bw2 = w2;
+                }
+            }
+        }
+    }
+    if (!active) return;
+    size_t pix = ((size_t)b * H + j) * W + i;
+    face_idx[pix] = (int64_t)bi;
+    if (FUSED) {
+        float d = 0.f, u = 0.f, v = 0.f;
+        if (bi >= 0) {
+            const float *zf = zb + (size_t)bi * 3 * zstride;
+            d = (bw0 * zf[0] + bw1 * zf[zstride]) + bw2 * zf[2 * zstride];
+            const float *ff = feat + ((size_t)(featB == 1 ? 0 : b) * F + bi) * 6;
+            u = (bw0 * ff[0] + bw1 * ff[2]) + bw2 * ff[4];
+            v = (bw0 * ff[1] + bw1 * ff[3]) + bw2 * ff[5];
+        }
+        out[pix] = d;
+        out_uv[pix * 2 + 0] = u;
+        out_uv[pix * 2 + 1] = v;
+        if (normals) {
+            int fnb = bi >= 0 ? bi : F - 1;   // python negative index: -1 -> last face
+            const float *nf = fnorm + ((size_t)b * F + fnb) * 3;
+            normals[pix * 3 + 0] = nf[0]; normals[pix * 3 + 1] = nf[1]; normals[pix * 3 + 2] = nf[2];
+        }
+    } else {
+        for (int c = 0; c < C; ++c) {
+            float val = 0.f;
+            if (bi >= 0) {
+                const float *ff = feat + ((size_t)(featB == 1 ? 0 : b) * F + bi) * 3 * C;
+                val = (bw0 * ff[0 * C + c] + bw1 * ff[1 * C + c]) + bw2 * ff[2 * C + c];
+            }
+            out[pix * C + c] = val;
+        }
+    }
+}
+
+extern "C" int64_t ctx_rasterize_ws_bytes(int32_t H, int32_t W, int32_t B, int32_t F)
+{
+    int64_t nt = (int64_t)cdiv(W, COARSE) * cdiv(H, COARSE);
+    return ((int64_t)B * nt * F + (int64_t)B * nt) * 4 + 256;
+}
+
+static int32_t raster_common(bool fused, int H, int W, const float *fz, int zstride, const float *fxy,
+                             const float *feat, int featB, int C, const float *fnorm, int B, int F, float mult,
+                             float eps, float *out, float *out_uv, int64_t *face_idx, float *normals, void *ws,
+                             int64_t ws_bytes, hipStream_t s)
+{
+    CTX_REQUIRE(fz && fxy && feat && out && face_idx && ws, "rasterize: null pointer");
+    CTX_REQUIRE(H > 0 && W > 0 && B > 0 && F > 0 && H <= 16384 && W <= 16384, "rasterize: bad sizes H=%d W=%d B=%d F=%d", H, W, B, F);
+    CTX_REQUIRE(ws_bytes >= ctx_rasterize_ws_bytes(H, W, B, F), "rasterize: workspace too small (%lld < %lld)",
+                (long long)ws_bytes, (long long)ctx_rasterize_ws_bytes(H, W, B, F));
+    int ntx = cdiv(W, COARSE), nty = cdiv(H, COARSE);
+    int *lists = (int *)ws;
+    int *counts = lists + (size_t)B * ntx * nty * F;
+    hipLaunchKernelGGL(k_raster_bin, dim3(ntx * nty, B), dim3(256), 0, s, H, W, fz, zstride, fxy, F, mult, ntx, nty, lists, counts);
+    dim3 grid(cdiv(W, FT_W), cdiv(H, FT_H), B);
+    if (fused)
+        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, H, W, fz, zstride, fxy, feat, featB, C, fnorm, F, mult, eps,
+                           ntx, nty, lists, counts, out, out_uv, face_idx, normals);
+    else
+        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, H, W, fz, zstride, fxy, feat, featB, C, fnorm, F, mult, eps,
+                           ntx, nty, lists, counts, out, out_uv, face_idx, normals);
+    CTX_CHECK_LAUNCH("rasterize");
+    return CTX_OK;
+}
+
+extern "C" int32_t ctx_rasterize_fwd(int32_t H, int32_t W, const float *face_z, const float *face_xy,
+                                     const float *feat, int32_t B, int32_t F, int32_t C, float multiplier,
+                                     float eps, float *out, int64_t *face_idx, void *ws, int64_t ws_bytes,
+                                     ctx_stream_t stream)
+{
+    CTX_REQUIRE(C >= 1 && C <= 64, "rasterize: C=%d unsupported", C);
+    return raster_common(false, H, W, face_z, 1, face_xy, feat, B, C, nullptr, B, F, multiplier, eps, out, nullptr,
+                         face_idx, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int32_t ctx_rasterize_fused(int32_t H, int32_t W, const float *fv_cam, const float *face_xy,
+                                       const float *uv_attr, int32_t Bu, const float *fnorm, int32_t B, int32_t F,
+                                       float multiplier, float eps, float *depth, float *uv, int64_t *face_idx,
+                                       float *normals, void *ws, int64_t ws_bytes, ctx_stream_t stream)
+{
+    CTX_REQUIRE(uv && (Bu == 1 || Bu == B), "rasterize_fused: uv null or Bu=%d not in {1,%d}", Bu, B);
+    CTX_REQUIRE((normals == nullptr) || (fnorm != nullptr), "rasterize_fused: normals requested without fnorm");
+    // z of vertex k of face f is fv_cam[b,f,k,2]: base +2, stride 3
+    return raster_common(true, H, W, fv_cam + 2, 3, face_xy, uv_attr, Bu, 2, fnorm, B, F, multiplier, eps, depth, uv,
+                         face_idx, normals, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// normalize_multiple_depth: partial min/max per (view, block) -> normalise.
+#define ND_BLOCKS 256
+__global__ __launch_bounds__(256) void k_depth_minmax(const float *__restrict__ d, int HW, float *__restrict__ part,
+                                                      int *__restrict__ flags)
+{
+    int b = blockIdx.y;
+    const float *p = d + (size_t)b * HW;
+    float mn = INFINITY, mx = -INFINITY;
+    int pos = 0, any = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += ND_BLOCKS * 256) {
+        float v = p[i];
+        if (v > 0.f) pos = 1;
+        if (v != 0.f) { any = 1; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    __shared__ float s_mn[4], s_mx[4];
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_mn[w] = mn; s_mx[w] = mx; }
+    if (__any(pos) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+        mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+        part[((size_t)b * ND_BLOCKS + blockIdx.x) * 2 + 0] = mn;
+        part[((size_t)b * ND_BLOCKS + blockIdx.x) * 2 + 1] = mx;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_depth_apply(const float *__restrict__ d, int HW, const float *__restrict__ part,
+                                                     const int *__restrict__ flags, float *__restrict__ out,
+                                                     int *__restrict__ status)
+{
+    int b = blockIdx.y;
+    float mn = part[((size_t)b * ND_BLOCKS + threadIdx.x) * 2 + 0];
+    float mx = part[((size_t)b * ND_BLOCKS + threadIdx.x) * 2 + 1];
+    mn = wave_min(mn); mx = wave_max(mx);
+    __shared__ float s_mn[4], s_mx[4];
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_mn[w] = mn; s_mx[w] = mx; }
+    __syncthreads();
+    mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+    mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+    float range = mx - mn;
+    if (status && b == 0 && blockIdx.x == 0 && threadIdx.x == 0)
+        status[0] = flags[0] ? 1 : (flags[1] ? 0 : 2);
+    const float *p = d + (size_t)b * HW;
+    float *o = out + (size_t)b * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        float v = p[i];
+        o[i] = (v != 0.f) ? (v - mn) / range : v;
+    }
+}
+
+extern "C" int64_t ctx_normalize_depth_ws_bytes(int32_t B) { return (int64_t)B * ND_BLOCKS * 2 * 4 + 16; }
+
+extern "C" int32_t ctx_normalize_depth(const float *depth, int32_t B, int32_t HW, float *out, void *ws,
+                                       int32_t *status, ctx_stream_t stream)
+{
+    CTX_REQUIRE(depth && out && ws && B > 0 && HW > 0, "normalize_depth: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    int *flags = (int *)ws;
+    float *part = (float *)ws + 4;
+    (void)hipMemsetAsync(flags, 0, 16, s);
+    hipLaunchKernelGGL(k_depth_minmax, dim3(ND_BLOCKS, B), dim3(256), 0, s, depth, HW, part, flags);
+    int nb = min(cdiv(HW, 256), 2048);
+    hipLaunchKernelGGL(k_depth_apply, dim3(nb, B), dim3(256), 0, s, depth, HW, part, flags, out, status);
+    CTX_CHECK_LAUNCH("normalize_depth");
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// texture_mapping == grid_sample(bilinear|nearest, align_corners=False, padding 'border').
+__device__ __forceinline__ float src_index(float g, int size)
+{
+    float c = ((g + 1.0f) * (float)size - 1.0f) / 2.0f;
+    return fminf((float)(size - 1), fmaxf(c, 0.0f));
+}
+
+__global__ __launch_bounds__(256) void k_texmap_fwd(const float *__restrict__ uv, const float *__restrict__ tex,
+                                                    int64_t HW, int C, int T, int Bt, int mode,
+                                                    const int64_t *__restrict__ mask_idx, float *__restrict__ out)
+{
+    int b = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        size_t pix = (size_t)b * HW + i;
+        float2 q = *(const float2 *)(uv + pix * 2);
+        const float *tb = tex + (Bt == 1 ? 0 : (size_t)b * C * T * T);
+        float ix = src_index(q.x * 2.0f - 1.0f, T), iy = src_index((1.0f - q.y) * 2.0f - 1.0f, T);
+        float msk = 1.0f;
+        if (mask_idx) msk = mask_idx[pix] > -1 ? 1.0f : 0.0f;
+        float *o = out + pix * C;
+        if (mode == 1) {
+            int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+            bool in = xn >= 0 && xn < T && yn >= 0 && yn < T;
+            for (int c = 0; c < C; ++c) {
+                float v = in ? tb[((size_t)c * T + yn) * T + xn] : 0.0f;
+                o[c] = mask_idx ? v * msk : v;
+            }
+            continue;
+        }
+        float fx = floorf(ix), fy = floorf(iy);
+        int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+        float wne = (ix - (float)x0) * ((float)y1 - iy);
+        float wsw = ((float)x1 - ix) * (iy - (float)y0);
+        float wse = (ix - (float)x0) * (iy - (float)y0);
+        bool bx0 = x0 >= 0 && x0 < T, bx1 = x1 >= 0 && x1 < T, by0 = y0 >= 0 && y0 < T, by1 = y1 >= 0 && y1 < T;
+        for (int c = 0; c < C; ++c) {
+            const float *tc = tb + (size_t)c * T * T;
+            float acc = 0.0f;
+            if (bx0 && by0) acc = acc + tc[(size_t)y0 * T + x0] * wnw;
+            if (bx1 && by0) acc = acc + tc[(size_t)y0 * T + x1] * wne;
+            if (bx0 && by1) acc = acc + tc[(size_t)y1 * T + x0] * wsw;
+            if (bx1 && by1) acc = acc + tc[(size_t)y1 * T + x1] * wse;
+            o[c] = mask_idx ? acc * msk : acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_texmap_bwd(const float *__restrict__ go, const float *__restrict__ uv,
+                                                    int64_t HW, int C, int T, const int64_t *__restrict__ mask_idx,
+                                                    float *__restrict__ gt)
+{
+    int b = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        size_t pix = (size_t)b * HW + i;
+        if (mask_idx && mask_idx[pix] < 0) continue;
+        float2 q = *(const float2 *)(uv + pix * 2);
+        float ix = src_index(q.x * 2.0f - 1.0f, T), iy = src_index((1.0f - q.y) * 2.0f - 1.0f, T);
+        float fx = floorf(ix), fy = floorf(iy);
+        int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+        float wne = (ix - (float)x0) * ((float)y1 - iy);
+        float wsw = ((float)x1 - ix) * (iy - (float)y0);
+        float wse = (ix - (float)x0) * (iy - (float)y0);
+        bool bx0 = x0 >= 0 && x0 < T, bx1 = x1 >= 0 && x1 < T, by0 = y0 >= 0 && y0 < T, by1 = y1 >= 0 && y1 < T;
+        for (int c = 0; c < C; ++c) {
+            float g = go[pix * C + c];
+            float *tc = gt + (size_t)c * T * T;
+            if (bx0 && by0) atomicAdd(tc + (size_t)y0 * T + x0, g * wnw);
+            if (bx1 && by0) atomicAdd(tc + (size_t)y0 * T + x1, g * wne);
+            if (bx0 && by1) atomicAdd(tc + (size_t)y1 * T + x0, g * wsw);
+            if (bx1 && by1) atomicAdd(tc + (size_t)y1 * T + x1, g * wse);
+        }
+    }
+}
+
+extern "C" int32_t ctx_texture_mapping_fwd(const float *uv, const float *tex, int32_t B, int32_t HW, int32_t C,
+                                           int32_t T, int32_t Bt, int32_t mode, const int64_t *mask_idx, float *out,
+                                           ctx_stream_t stream)
+{
+    CTX_REQUIRE(uv && tex && out, "texture_mapping: null pointer");
+    CTX_REQUIRE(B > 0 && HW > 0 && C > 0 && T > 0 && (Bt == 1 || Bt == B) && (mode == 0 || mode == 1),
+                "texture_mapping: bad args B=%d HW=%d C=%d T=%d Bt=%d mode=%d", B, HW, C, T, Bt, mode);
+    int nb = min(cdiv(HW, 256), 4096);
+    hipLaunchKernelGGL(k_texmap_fwd, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, uv, tex, (int64_t)HW, C, T, Bt, mode, mask_idx, out);
+    CTX_CHECK_LAUNCH("texture_mapping_fwd");
+    return CTX_OK;
+}
+
+extern "C" int32_t ctx_texture_mapping_bwd(const float *grad_out, const float *uv, int32_t B, int32_t HW, int32_t C,
+                                           int32_t T, const int64_t *mask_idx, float *grad_tex, ctx_stream_t stream)
+{
+    CTX_REQUIRE(grad_out && uv && grad_tex && B > 0 && HW > 0 && C > 0 && T > 0, "texture_mapping_bwd: bad args");
+    int nb = min(cdiv(HW, 256), 4096);
+    hipLaunchKernelGGL(k_texmap_bwd, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, grad_out, uv, (int64_t)HW, C, T, mask_idx, grad_tex);
+    CTX_CHECK_LAUNCH("texture_mapping_bwd");
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// View weights.  max over pixels of fnz[b, face_idx[b,p]] per face == max over the views in which
+// the face is visible, so phase 0 only marks (view, face) visibility (idempotent byte stores, no
+// atomics) and then reduces B values per face.
+__global__ __launch_bounds__(256) void k_vw_mark(const int64_t *__restrict__ face_idx, int64_t HW, int F,
+                                                 uint8_t *__restrict__ vis)
+{
+    int b = blockIdx.y;
+    const int64_t *p = face_idx + (size_t)b * HW;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < HW; i += (int64_t)gridDim.x * 512) {
+        int64_t f0 = p[i];
+        int64_t f1 = (i + 1 < HW) ? p[i + 1] : -1;
+        if (f0 >= 0) vis[(size_t)b * F + f0] = 1;
+        if (f1 >= 0) vis[(size_t)b * F + f1] = 1;
+    }
+}
+
+__global__ void k_vw_reduce(const uint8_t *__restrict__ vis, const float *__restrict__ fnz, int B, int F,
+                            float *__restrict__ max_z)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float m = max_z[f];
+    for (int b = 0; b < B; ++b)
+        if (vis[(size_t)b * F + f]) {
+            float z = fnz[(size_t)b * F + f];
+            if (z > m) m = z;
+        }
+    max_z[f] = m;
+}
+
+__global__ __launch_bounds__(256) void k_vw_mask(const int64_t *__restrict__ face_idx, const float *__restrict__ fnz,
+                                                 const float *__restrict__ max_z, int64_t HW, int F,
+                                                 uint8_t *__restrict__ mask)
+{
+    int b = blockIdx.y;
+    const int64_t *p = face_idx + (size_t)b * HW;
+    uint8_t *o = mask + (size_t)b * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        int64_t f = p[i];
+        uint8_t m = 1;
+        if (f >= 0) m = !(fnz[(size_t)b * F + f] < max_z[f]);
+        o[i] = m;
+    }
+}
+
+extern "C" int32_t ctx_view_weights_max(const int64_t *face_idx, const float *fnz, int32_t B, int32_t HW, int32_t F,
+                                        float *max_z, void *vis_ws, ctx_stream_t stream)
+{
+    CTX_REQUIRE(face_idx && fnz && max_z && vis_ws && B > 0 && HW > 0 && F > 0, "view_weights_max: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(vis_ws, 0, (size_t)B * F, s);
+    int nb = min(cdiv(HW, 512), 2048);
+    hipLaunchKernelGGL(k_vw_mark, dim3(nb, B), dim3(256), 0, s, face_idx, (int64_t)HW, F, (uint8_t *)vis_ws);
+    hipLaunchKernelGGL(k_vw_reduce, dim3(cdiv(F, 256)), dim3(256), 0, s, (const uint8_t *)vis_ws, fnz, B, F, max_z);
+    CTX_CHECK_LAUNCH("view_weights_max");
+    return CTX_OK;
+}
+
+extern "C" int32_t ctx_view_weights_mask(const int64_t *face_idx, const float *fnz, const float *max_z, int32_t B,
+                                         int32_t HW, int32_t F, uint8_t *mask, ctx_stream_t stream)
+{
+    CTX_REQUIRE(face_idx && fnz && max_z && mask && B > 0 && HW > 0 && F > 0, "view_weights_mask: bad args");
+    int nb = min(cdiv(HW, 256), 4096);
+    hipLaunchKernelGGL(k_vw_mask, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, face_idx, fnz, max_z, (int64_t)HW, F, mask);
+    CTX_CHECK_LAUNCH("view_weights_mask");
+    return CTX_OK;
+}
+
+// create_face_view_map: ordered stream compaction (count -> scan -> write).
+__global__ __launch_bounds__(256) void k_fvm_count(const int64_t *__restrict__ fi, int64_t N, int *__restrict__ counts)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool v = i < N && fi[i] >= 0;
+    unsigned long long m = __ballot(v);
+    __shared__ int s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(1024) void k_fvm_scan(int *__restrict__ counts, int64_t nblk, int64_t *__restrict__ base,
+                                                   int64_t *__restrict__ n_rows)
+{
+    // single workgroup, sequential chunks of 1024 with a running carry
+    __shared__ int64_t s[1024];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < nblk; c0 += 1024) {
+        int64_t i = c0 + threadIdx.x;
+        int64_t v = i < nblk ? counts[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int64_t t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblk) base[i] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_rows[0] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_fvm_write(const int64_t *__restrict__ fi, int64_t N, int64_t HW, int W,
+                                                   const int64_t *__restrict__ base, int64_t *__restrict__ rows)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t f = i < N ? fi[i] : -1;
+    bool v = f >= 0;
+    unsigned long long m = __ballot(v);
+    __shared__ int s[4];
+    int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s[w] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < w; ++k) off += s[k];
+    if (v) {
+        int64_t r = base[blockIdx.x] + off + __popcll(m & ((1ull << lane) - 1));
+        int64_t view = i / HW, pix = i % HW;
+        int64_t *o = rows + r * 4;
+        o[0] = f; o[1] = view; o[2] = pix / W; o[3] = pix % W;
+    }
+}
+
+extern "C" int64_t ctx_face_view_map_ws_bytes(int32_t B, int32_t H, int32_t W)
+{
+    int64_t nblk = cdiv64((int64_t)B * H * W, 256);
+    return nblk * 4 + nblk * 8 + 64;
+}
+
+extern "C" int32_t ctx_face_view_map(const int64_t *face_idx, int32_t B, int32_t H, int32_t W, int64_t *rows,
+                                     int64_t *n_rows, void *ws, ctx_stream_t stream)
+{
+    CTX_REQUIRE(face_idx && rows && n_rows && ws && B > 0 && H > 0 && W > 0, "face_view_map: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t N = (int64_t)B * H * W, nblk = cdiv64(N, 256);
+    int64_t *base = (int64_t *)ws;
+    int *counts = (int *)(base + nblk);
+    hipLaunchKernelGGL(k_fvm_count, dim3((unsigned)nblk), dim3(256), 0, s, face_idx, N, counts);
+    hipLaunchKernelGGL(k_fvm_scan, dim3(1), dim3(1024), 0, s, counts, nblk, base, n_rows);
+    hipLaunchKernelGGL(k_fvm_write, dim3((unsigned)nblk), dim3(256), 0, s, face_idx, N, (int64_t)H * W, W, base, rows);
+    CTX_CHECK_LAUNCH("face_view_map");
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Positional encoding (unfused form, kept for API parity with get_embedder; the MLP kernel fuses it).
+__global__ __launch_bounds__(256) void k_embed(const float *__restrict__ x, int64_t N, int d, int L, float *__restrict__ out)
+{
+    int od = d * (1 + 2 * L);
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+        float *o = out + n * od;
+        for (int c = 0; c < d; ++c) {
+            float v = x[n * d + c];
+            o[c] = v;
+            float fr = 1.0f;
+            for (int l = 0; l < L; ++l) {
+                float a = v * fr;
+                o[d + (2 * l) * d + c] = sinf(a);
+                o[d + (2 * l + 1) * d + c] = cosf(a);
+                fr = fr * 2.0f;
+            }
+        }
+    }
+}
+
+extern "C" int32_t ctx_embed_fwd(const float *x, int64_t N, int32_t d, int32_t L, float *out, ctx_stream_t stream)
+{
+    CTX_REQUIRE(x && out && N > 0 && d > 0 && L >= 0, "embed: bad args");
+    int nb = (int)((N + 255) / 256 < 4096 ? (N + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_embed, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, N, d, L, out);
+    CTX_CHECK_LAUNCH("embed");
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rays + volume-render compositing.
+__global__ __launch_bounds__(256) void k_get_rays(int H, int W, float fx, float fy, float cx, float cy,
+                                                  const float *__restrict__ c2w, float *__restrict__ ro,
+                                                  float *__restrict__ rd)
+{
+    int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= (int64_t)H * W) return;
+    int j = (int)(n / W), i = (int)(n % W);
+    float dx = ((float)i - cx) / fx, dy = -((float)j - cy) / fy, dz = -1.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        // torch.sum(dirs[..., None, :] * c2w[:3,:3], -1): sequential left-to-right sum
+        rd[n * 3 + r] = (dx * c2w[r * 4 + 0] + dy * c2w[r * 4 + 1]) + dz * c2w[r * 4 + 2];
+        ro[n * 3 + r] = c2w[r * 4 + 3];
+    }
+}
+
+extern "C" int32_t ctx_get_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float *c2w,
+                                float *rays_o, float *rays_d, ctx_stream_t stream)
+{
+    CTX_REQUIRE(c2w && rays_o && rays_d && H > 0 && W > 0, "get_rays: bad args");
+    hipLaunchKernelGGL(k_get_rays, dim3((unsigned)cdiv64((int64_t)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                       H, W, fx, fy, cx, cy, c2w, rays_o, rays_d);
+    CTX_CHECK_LAUNCH("get_rays");
+    return CTX_OK;
+}
+
+// One wavefront per ray: lane s holds sample s of the current 64-sample chunk.  Transmittance is an
+// exclusive prefix product across lanes (6 shuffle steps), colour/depth/acc are wave sums.
+__global__ __launch_bounds__(256) void k_composite(const float4 *__restrict__ raw, const float *__restrict__ z,
+                                                   const float *__restrict__ rays_d, int64_t R, int S, int white,
+                                                   float *__restrict__ rgb, float *__restrict__ disp,
+                                                   float *__restrict__ acc, float *__restrict__ weights,
+                                                   float *__restrict__ depth)
+{
+    int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t r = wave; r < R; r += nwaves) {
+        float d0 = rays_d[r * 3 + 0], d1 = rays_d[r * 3 + 1], d2 = rays_d[r * 3 + 2];
+        float nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+        float Tc = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, a = 0.f;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            int s = s0 + lane;
+            bool ok = s < S;
+            float4 q = ok ? raw[r * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float zv = ok ? z[r * S + s] : 0.f;
+            float zn = (s + 1 < S) ? z[r * S + s + 1] : 0.f;
+            float dist = (s + 1 < S) ? (zn - zv) : 1e10f;
+            dist = dist * nrm;
+            float sigma = q.w > 0.f ? q.w : 0.f;
+            float alpha = ok ? 1.0f - expf(-sigma * dist) : 0.f;
+            float t = ok ? (1.0f - alpha) + 1e-10f : 1.0f;
+            // inclusive prefix product
+            float inc = t;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                float up = __shfl_up(inc, o, 64);
+                if (lane >= o) inc = inc * up;
+            }
+            float exc = __shfl_up(inc, 1, 64);
+            if (lane == 0) exc = 1.0f;
+            float w = alpha * (Tc * exc);
+            if (weights && ok) weights[r * S + s] = w;
+            c0 += w * (1.0f / (1.0f + expf(-q.x)));
+            c1 += w * (1.0f / (1.0f + expf(-q.y)));
+            c2 += w * (1.0f / (1.0f + expf(-q.z)));
+            dep += w * zv;
+            a += w;
+            Tc = Tc * __shfl(inc, 63, 64);
+        }
+        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); dep = wave_sum(dep); a = wave_sum(a);
+        if (lane == 0) {
+            if (white) { c0 += 1.0f - a; c1 += 1.0f - a; c2 += 1.0f - a; }
+            rgb[r * 3 + 0] = c0; rgb[r * 3 + 1] = c1; rgb[r * 3 + 2] = c2;
+            depth[r] = dep; acc[r] = a;
+            float qd = dep / a;
+            float dv = 1.0f / (qd > 1e-10f ? qd : 1e-10f);
+            disp[r] = (qd != qd) ? qd : dv;
+        }
+    }
+}
+
+extern "C" int32_t ctx_raymarch_composite_fwd(const float *raw, const float *z_vals, const float *rays_d, int64_t R,
+                                              int32_t S, int32_t white_bkgd, float *rgb, float *disp, float *acc,
+                                              float *weights, float *depth, ctx_stream_t stream)
+{
+    CTX_REQUIRE(raw && z_vals && rays_d && rgb && disp && acc && depth && R > 0 && S > 0, "raymarch: bad args");
+    int64_t nb = cdiv64(R, 4);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(k_composite, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4 *)raw, z_vals,
+                       rays_d, R, S, white_bkgd, rgb, disp, acc, weights, depth);
+    CTX_CHECK_LAUNCH("raymarch_composite");
+    return CTX_OK;
+}

@@ -1,0 +1,176 @@
+"""Texture field + ray helpers: drop-in for src/run_nerf_helpers.py (get_embedder, NeRF2D, get_rays,
+ndc_rays, sample_pdf) with the hot ops on libctxnerf.so.
+
+NeRF2D keeps the reference's parameter names (`pts_linears.{i}.{weight,bias}`, `output_linear.*`) and
+initialisation order so a reference state_dict loads unchanged and a seeded construction gives the same
+weights.  forward(embedded) runs the fused fp32-MFMA kernel; `texture_map(res)` is the fully fused
+uv -> embed -> MLP -> (tanh+1)/2 path used by TexturedMeshModel.get_texture_map.
+Forward only on the HIP path this round (SDS backward is SURVEY §8f n3).
+"""
+import ctypes as C
+import numpy as np
+import torch
+import torch.nn as nn
+from . import _lib as L
+
+img2mse = lambda x, y: torch.mean((x - y) ** 2)
+mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device))
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+class Embedder:
+    def __init__(self, input_dims=2, multires=10):
+        self.input_dims, self.multires = input_dims, multires
+        self.out_dim = input_dims * (1 + 2 * multires)
+
+    def embed(self, inputs):
+        lib = L.load()
+        x = L.f32c(inputs).reshape(-1, self.input_dims)
+        out = torch.empty(x.shape[0], self.out_dim, device=x.device)
+        L.check(lib.ctx_embed_fwd(L.ptr(x, torch.float32, "inputs"), x.shape[0], self.input_dims, self.multires,
+                                  L.ptr(out), L.stream()))
+        return out.reshape(*inputs.shape[:-1], self.out_dim)
+
+
+def get_embedder(multires, i=0):
+    if i == -1:
+        return nn.Identity(), 2
+    eo = Embedder(2, multires)
+    return (lambda x, eo=eo: eo.embed(x)), eo.out_dim
+
+
+class NeRF2D(nn.Module):
+    def __init__(self, D=8, W=256, input_ch=3, output_ch=4, skips=[4]):
+        super().__init__()
+        self.D, self.W, self.input_ch, self.output_ch, self.skips = D, W, input_ch, output_ch, list(skips)
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(input_ch, W)] +
+            [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + input_ch, W) for i in range(D - 1)])
+        self.output_linear = nn.Linear(W, output_ch)
+        for layer in self.pts_linears:
+            nn.init.kaiming_normal_(layer.weight, mode='fan_in', nonlinearity='relu')
+        nn.init.kaiming_normal_(self.output_linear.weight, mode='fan_in', nonlinearity='relu')
+        self._packed = None
+        self._packed_version = None
+
+    # -- weight packing (cached; invalidated by in-place parameter updates via _version) --------------
+    def _version(self):
+        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def packed(self):
+        if len(self.skips) != 1:
+            raise L.CtxError("NeRF2D HIP path supports exactly one skip connection (the reference uses skips=[4])")
+        v = self._version()
+        if self._packed is None or self._packed_version != v:
+            lib = L.load()
+            dev = self.output_linear.weight.device
+            n = lib.ctx_uvmlp_packed_bytes(self.D, self.W, self.input_ch, self.output_ch, self.skips[0])
+            if n < 0:
+                raise L.CtxError(f"NeRF2D(D={self.D},W={self.W},input_ch={self.input_ch},output_ch={self.output_ch}) "
+                                 "is outside the fused kernel's envelope (W in 64/128/256, input_ch<=48, output_ch<=4)")
+            blob = torch.empty(n, dtype=torch.uint8, device=dev)
+            layers = list(self.pts_linears) + [self.output_linear]
+            ws = [L.f32c(l.weight.detach()) for l in layers]
+            bs = [L.f32c(l.bias.detach()) for l in layers]
+            wp = (C.c_void_p * len(ws))(*[L.ptr(w, torch.float32, "weight").value for w in ws])
+            bp = (C.c_void_p * len(bs))(*[L.ptr(b, torch.float32, "bias").value for b in bs])
+            L.check(lib.ctx_uvmlp_pack(wp, bp, self.D, self.W, self.input_ch, self.output_ch, self.skips[0],
+                                       L.ptr(blob), L.stream()))
+            self._packed, self._packed_version = blob, v
+        return self._packed
+
+    def _run(self, uv, emb, N, res, want_tex):
+        lib = L.load()
+        blob = self.packed()
+        dev = blob.device
+        Lf = (self.input_ch // 2 - 1) // 2
+        raw = torch.empty(N, self.output_ch, device=dev)
+        tex = torch.empty(self.output_ch, N, device=dev) if want_tex else None
+        L.check(lib.ctx_uvmlp_fwd(L.ptr(uv), L.ptr(emb), N, res, L.ptr(blob), self.D, self.W, Lf, self.output_ch,
+                                  self.skips[0], L.ptr(raw), L.ptr(tex), L.stream()))
+        return raw, tex
+
+    def forward(self, x):
+        """x: embedded inputs [N, input_ch] (reference seam) -> raw outputs [N, output_ch]."""
+        e = L.f32c(x).reshape(-1, self.input_ch)
+        raw, _ = self._run(None, e, e.shape[0], 0, False)
+        return raw.reshape(*x.shape[:-1], self.output_ch)
+
+    def forward_uv(self, uv):
+        """Fused embed+MLP on raw uv [N,2]."""
+        u = L.f32c(uv).reshape(-1, 2)
+        raw, _ = self._run(u, None, u.shape[0], 0, False)
+        return raw
+
+    def texture_map(self, res):
+        """textured_mesh.py:266-301 fused: -> (texture [1,C,res,res] in [0,1], mlp_output [res*res, C])."""
+        raw, tex = self._run(None, None, res * res, res, True)
+        return tex.reshape(1, self.output_ch, res, res), raw
+
+
+# ---- ray helpers (dead code in the reference, named by north_star) ------------------------------------
+def get_rays(H, W, K, c2w):
+    lib = L.load()
+    c = L.f32c(c2w[:3, :4])
+    ro = torch.empty(H, W, 3, device=c.device)
+    rd = torch.empty(H, W, 3, device=c.device)
+    L.check(lib.ctx_get_rays(H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), L.ptr(c, torch.float32, "c2w"),
+                             L.ptr(ro), L.ptr(rd), L.stream()))
+    return ro, rd
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2. * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    dev = bins.device
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if det:
+        u = torch.linspace(0., 1., steps=N_samples, device=dev).expand(list(cdf.shape[:-1]) + [N_samples])
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [N_samples], device=dev)
+    if pytest:
+        np.random.seed(0)
+        new_shape = list(cdf.shape[:-1]) + [N_samples]
+        u = np.broadcast_to(np.linspace(0., 1., N_samples), new_shape) if det else np.random.rand(*new_shape)
+        u = torch.tensor(np.ascontiguousarray(u), dtype=torch.float32, device=dev)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.max(torch.zeros_like(inds - 1), inds - 1)
+    above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
+    inds_g = torch.stack([below, above], -1)
+    matched_shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
+    """nerf-pytorch raw2outputs (the compositing step src/run_nerf_helpers.py:130-133 points to), as one
+    wave-per-ray HIP kernel -> (rgb_map, disp_map, acc_map, weights, depth_map)."""
+    if raw_noise_std != 0:
+        raise L.CtxError("raw2outputs: raw_noise_std != 0 is not implemented on the HIP path")
+    lib = L.load()
+    r, z, d = L.f32c(raw), L.f32c(z_vals), L.f32c(rays_d)
+    R, S, _ = r.shape
+    dev = r.device
+    rgb = torch.empty(R, 3, device=dev); disp = torch.empty(R, device=dev); acc = torch.empty(R, device=dev)
+    w = torch.empty(R, S, device=dev); depth = torch.empty(R, device=dev)
+    L.check(lib.ctx_raymarch_composite_fwd(L.ptr(r, torch.float32, "raw"), L.ptr(z), L.ptr(d), R, S, int(white_bkgd), L.ptr(rgb),
+                                           L.ptr(disp), L.ptr(acc), L.ptr(w), L.ptr(depth), L.stream()))
+    return rgb, disp, acc, w, depth

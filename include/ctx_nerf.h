@@ -1,0 +1,199 @@
+/*
+ * ctx_nerf.h — C-ABI of libctxnerf.so: the MI355X (gfx950) hot path of ConTEXTure's per-view
+ * texture-painting loop.
+ *
+ * The reference (zaiisao/ConTEXTure-NeRF) has no FFI of its own: its hot ops live in third-party
+ * Python packages (kaolin, torch-scatter, diffusers).  Each entry point below replaces the
+ * third-party call the reference makes at the cited file:line; the Python shims in
+ * contexture-nerf_amd/ keep those call signatures (INTEGRATION.md shows the ctypes binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major memory owned by the caller
+ *     (PyTorch allocates; the library never frees or retains it beyond the call, except the
+ *     weight/workspace blobs explicitly bound to a ctx_unet_t);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing syncs;
+ *   - return 0 = OK, negative = error (CTX_E_*); ctx_last_error() gives a thread-local message;
+ *   - int64 face indices follow the reference's dtype (kaolin returns int64, -1 = background).
+ */
+#ifndef CTX_NERF_H
+#define CTX_NERF_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTX_OK 0
+#define CTX_E_ARG (-1)      /* bad shape / null pointer / unsupported size */
+#define CTX_E_LAUNCH (-2)   /* hipGetLastError() after launch */
+#define CTX_E_STATE (-3)    /* handle not bound / wrong phase */
+
+typedef void *ctx_stream_t;
+
+int32_t ctx_version(void);
+const char *ctx_last_error(void);
+/* Device check used by the Python loader: 0 when a gfx950 device is current. */
+int32_t ctx_device_check(void);
+
+/* ---- raster path ------------------------------------------------------------------------- */
+/* kal.render.mesh.prepare_vertices  (src/models/render.py:112-113; textured_mesh.py:167-168)
+   verts[B,V,3] faces[F,3] cam[B,4,3] proj3[3] -> fv_cam[B,F,3,3] fv_img[B,F,3,2] fnorm[B,F,3] */
+int32_t ctx_prepare_vertices(const float *verts, const int64_t *faces, const float *cam,
+                             const float *proj3, int32_t B, int32_t V, int32_t F,
+                             float *fv_cam, float *fv_img, float *fnorm,
+                             void *ws /* B*V*5 floats */, ctx_stream_t stream);
+
+/* Scratch for the per-coarse-tile face lists of the two rasterise entry points. */
+int64_t ctx_rasterize_ws_bytes(int32_t H, int32_t W, int32_t B, int32_t F);
+/* kal.render.mesh.rasterize  (src/models/render.py:115-120; textured_mesh.py:170-175)
+   face_z[B,F,3] face_xy[B,F,3,2] feat[B,F,3,C] -> out[B,H,W,C] face_idx[B,H,W]  (C <= 64) */
+int32_t ctx_rasterize_fwd(int32_t H, int32_t W, const float *face_z, const float *face_xy,
+                          const float *feat, int32_t B, int32_t F, int32_t C,
+                          float multiplier, float eps, float *out, int64_t *face_idx,
+                          void *ws, int64_t ws_bytes, ctx_stream_t stream);
+
+/* The reference rasterises twice per render (depth pass, then UV pass: render.py:115 and :119).
+   Fused single pass: depth[B,H,W] (feature = z), uv[B,H,W,2], face_idx[B,H,W], and optionally the
+   gathered face normals normals[B,H,W,3] (render.py:150-157; background reads the LAST face).
+   fv_cam[B,F,3,3] supplies z (= fv_cam[...,2]); uv_attr[Bu,F,3,2] with Bu in {1,B}. */
+int32_t ctx_rasterize_fused(int32_t H, int32_t W, const float *fv_cam, const float *face_xy,
+                            const float *uv_attr, int32_t Bu, const float *fnorm /*nullable*/,
+                            int32_t B, int32_t F, float multiplier, float eps,
+                            float *depth, float *uv, int64_t *face_idx, float *normals /*nullable*/,
+                            void *ws, int64_t ws_bytes, ctx_stream_t stream);
+
+/* Renderer.normalize_multiple_depth (src/models/render.py:48-74).  ws: ctx_normalize_depth_ws_bytes(B).
+   status[0] (device int32, nullable): 0 ok, 1 positive depth present, 2 all-zero (the reference's
+   two asserts, render.py:49-50). */
+int64_t ctx_normalize_depth_ws_bytes(int32_t B);
+int32_t ctx_normalize_depth(const float *depth, int32_t B, int32_t HW, float *out,
+                            void *ws, int32_t *status, ctx_stream_t stream);
+
+/* kal.render.mesh.texture_mapping (src/models/render.py:135) == grid_sample(align_corners=False,
+   padding 'border'); tex[Bt,C,T,T] with Bt in {1,B}; mode 0 bilinear, 1 nearest; out[B,HW,C].
+   mask_idx (nullable, int64[B,HW]): when given, out *= (face_idx > -1)   (render.py:133,141). */
+int32_t ctx_texture_mapping_fwd(const float *uv, const float *tex, int32_t B, int32_t HW,
+                                int32_t C, int32_t T, int32_t Bt, int32_t mode,
+                                const int64_t *mask_idx, float *out, ctx_stream_t stream);
+/* autograd of the above w.r.t. the (expanded) atlas: grad_tex[C,T,T] += ...  (caller zeroes). */
+int32_t ctx_texture_mapping_bwd(const float *grad_out, const float *uv, int32_t B, int32_t HW,
+                                int32_t C, int32_t T, const int64_t *mask_idx, float *grad_tex,
+                                ctx_stream_t stream);
+
+/* ---- view weights: torch_scatter.scatter_max seam (src/training/trainer.py:213-249) ------- */
+/* phase 0: max_z[f] = max(max_z[f], fnz[b,f]) over pixels of the B local views showing f.
+   Caller pre-fills max_z with -inf; between the phases a multi-GPU caller all-reduces(MAX). */
+int32_t ctx_view_weights_max(const int64_t *face_idx, const float *fnz, int32_t B, int32_t HW,
+                             int32_t F, float *max_z, void *vis_ws /* B*F bytes */, ctx_stream_t stream);
+/* phase 1: mask[b,p] = !(fnz[b,f] < max_z[f]) for f>=0, 1 for background. */
+int32_t ctx_view_weights_mask(const int64_t *face_idx, const float *fnz, const float *max_z,
+                              int32_t B, int32_t HW, int32_t F, uint8_t *mask, ctx_stream_t stream);
+/* ConTEXTure.create_face_view_map (trainer.py:155-211): rows (face,view,i,j) of valid pixels in
+   (view, row, col) order.  ws: ctx_face_view_map_ws_bytes.  n_rows: device int64[1]. */
+int64_t ctx_face_view_map_ws_bytes(int32_t B, int32_t H, int32_t W);
+int32_t ctx_face_view_map(const int64_t *face_idx, int32_t B, int32_t H, int32_t W,
+                          int64_t *rows /*[B*H*W,4] capacity*/, int64_t *n_rows, void *ws,
+                          ctx_stream_t stream);
+
+/* ---- texture field: get_embedder / NeRF2D (src/run_nerf_helpers.py:15-135) ---------------- */
+/* embed(x[N,d]) -> [N, d*(1+2L)], order [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]. */
+int32_t ctx_embed_fwd(const float *x, int64_t N, int32_t d, int32_t L, float *out, ctx_stream_t stream);
+/* Bytes of the packed-weight blob for NeRF2D(D,W,input_ch,output_ch,skip). */
+int64_t ctx_uvmlp_packed_bytes(int32_t D, int32_t W, int32_t input_ch, int32_t output_ch, int32_t skip);
+/* Pack nn.Linear weights: ws[i] -> device float [out_i,in_i], bs[i] -> device float [out_i];
+   index D is output_linear. */
+int32_t ctx_uvmlp_pack(const float *const *ws, const float *const *bs, int32_t D, int32_t W,
+                       int32_t input_ch, int32_t output_ch, int32_t skip, void *packed,
+                       ctx_stream_t stream);
+/* Fused  embed(uv) -> NeRF2D -> raw[N,3]  (+ optional tex_chw[3,N] = (tanh(raw)+1)/2 laid out as the
+   [1,3,res,res] atlas of textured_mesh.py:298-301).  uv nullable: then uv = the res x res 'xy'
+   meshgrid of linspace(0,1,res) (textured_mesh.py:269-273), N = res*res. */
+/* emb (nullable): precomputed embedding [N, 2*(1+2L)] as returned by embed(); when given it is
+   loaded instead of being recomputed from uv (keeps the NeRF2D.forward(embedded) seam). */
+int32_t ctx_uvmlp_fwd(const float *uv /*nullable*/, const float *emb /*nullable*/, int64_t N, int32_t res, const void *packed,
+                      int32_t D, int32_t W, int32_t L, int32_t output_ch, int32_t skip,
+                      float *raw, float *tex_chw /*nullable*/, ctx_stream_t stream);
+
+/* ---- ray path (north_star; dead/absent in the reference) ------------------------ */
+/* get_rays (run_nerf_helpers.py:139-148): K row-major [3,3] host floats passed by value fields. */
+int32_t ctx_get_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy,
+                     const float *c2w /*[3,4] device*/, float *rays_o, float *rays_d, ctx_stream_t stream);
+/* nerf-pytorch raw2outputs: raw[R,S,4] z[R,S] rays_d[R,3] -> rgb[R,3] disp[R] acc[R]
+   weights[R,S] (nullable) depth[R]. */
+int32_t ctx_raymarch_composite_fwd(const float *raw, const float *z_vals, const float *rays_d,
+                                   int64_t R, int32_t S, int32_t white_bkgd, float *rgb, float *disp,
+                                   float *acc, float *weights, float *depth, ctx_stream_t stream);
+
+/* ---- UNet denoise engine (src/stable_diffusion_depth.py:422-430,514) ----------------------- */
+typedef struct ctx_unet ctx_unet_t;
+typedef struct {
+    int32_t in_channels, out_channels;
+    int32_t n_levels;            /* <= 4 */
+    int32_t block_out_channels[4];
+    int32_t heads[4];
+    int32_t down_attn[4], up_attn[4];
+    int32_t layers_per_block;
+    int32_t cross_attention_dim;
+    int32_t groups;
+    float norm_eps;
+} ctx_unet_config_t;
+
+ctx_unet_t *ctx_unet_create(const ctx_unet_config_t *cfg);
+void ctx_unet_destroy(ctx_unet_t *u);
+/* Parameter table in diffusers state_dict naming ("down_blocks.0.resnets.0.conv1.weight", ...). */
+int32_t ctx_unet_param_count(const ctx_unet_t *u);
+const char *ctx_unet_param_name(const ctx_unet_t *u, int32_t i);
+int32_t ctx_unet_param_shape(const ctx_unet_t *u, int32_t i, int64_t shape4[4]); /* returns ndim */
+int64_t ctx_unet_weight_bytes(const ctx_unet_t *u);
+int64_t ctx_unet_workspace_bytes(const ctx_unet_t *u, int32_t B, int32_t H, int32_t W, int32_t ctx_len);
+/* Bind caller-allocated blobs (256-B aligned). */
+int32_t ctx_unet_bind(ctx_unet_t *u, void *weights, void *workspace, int64_t workspace_bytes);
+/* Convert + repack parameter i from fp32 [diffusers layout] into the fp16 weight blob. */
+int32_t ctx_unet_set_param(ctx_unet_t *u, int32_t i, const float *src, ctx_stream_t stream);
+/* sample[B,Cin,H,W] f32 NCHW, timestep: device float[1] (graph-replay friendly), ctx[B,L,D] f32
+   -> out[B,Cout,H,W] f32 NCHW.  Computes in fp16 with fp32 accumulation/statistics. */
+int32_t ctx_unet_forward(ctx_unet_t *u, const float *sample, const float *timestep, const float *ctx,
+                         int32_t B, int32_t H, int32_t W, int32_t ctx_len, float *out, ctx_stream_t stream);
+/* Per-kernel accounting of the last forward: number of launches and algorithmic FLOPs by class
+   (0 gemm/conv MFMA, 1 attention MFMA, 2 other). */
+int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops);
+
+/* Building blocks, exported for unit parity tests (fp16 tensors passed as uint16 bit patterns). */
+/* C[M,N] = A[M,K] @ Wt[N,K]^T (+bias[N]) (+residual[M,N]); K%32==0, N%8==0. */
+int32_t ctx_gemm_f16(const void *A, const void *Wt, const void *bias, const void *residual,
+                     int32_t M, int32_t N, int32_t K, void *C, ctx_stream_t stream);
+/* x[B,H,W,Cin] (NHWC f16) * w[Cout,3,3,Cin] stride s pad 1 (+bias) (+rowbias[B,Cout]) (+res) -> [B,Ho,Wo,Cout];
+   upsample=1: nearest x2 of x first (Upsample2D). */
+int32_t ctx_conv3x3_f16(const void *x, const void *w, const void *bias, const void *rowbias,
+                        const void *residual, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                        int32_t Cout, int32_t stride, int32_t upsample, void *y, ctx_stream_t stream);
+/* GroupNorm(+SiLU) over NHWC f16; stats_ws: B*groups*2 floats. */
+int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const void *beta, int32_t B, int32_t HW,
+                          int32_t C, int32_t groups, float eps, int32_t silu, void *y, void *stats_ws,
+                          ctx_stream_t stream);
+int32_t ctx_layernorm_f16(const void *x, const void *gamma, const void *beta, int64_t rows, int32_t C,
+                          float eps, void *y, ctx_stream_t stream);
+/* softmax(Q K^T * scale) V; Q[B,Sq,heads*64], K[B,Skv,heads*64], V likewise (f16) -> O[B,Sq,heads*64]. */
+int32_t ctx_attention_f16(const void *Q, const void *K, const void *V, int32_t B, int32_t Sq, int32_t Skv,
+                          int32_t heads, int32_t q_stride, int32_t kv_stride, float scale, void *O,
+                          int32_t o_stride, ctx_stream_t stream);
+/* GEGLU: y[M,C4] = h[:, :C4] * gelu(h[:, C4:])  for h[M,2*C4] f16. */
+int32_t ctx_geglu_f16(const void *h, int64_t M, int32_t C4, void *y, ctx_stream_t stream);
+
+/* CFG combine + PNDM/PLMS update fused (stable_diffusion_depth.py:428-430,514; diffusers PNDMScheduler
+   step_plms with skip_prk_steps).  eps_pair[2,n] (uncond, text); ets[4,n] history ring (newest at
+   slot `head`); coef[4] linear-multistep weights for (e_t, e_t-1, e_t-2, e_t-3) after insertion;
+   sample_coeff, eps_coeff from _get_prev_sample; x[n] updated in place; also writes the blended
+   epsilon into ets[head]. mode 0: normal; 1: second call of the first step (average with ets[head],
+   use cur_sample_ws as x). */
+int32_t ctx_cfg_plms_step(const float *eps_pair, int64_t n, float guidance, float *ets, int32_t head,
+                          const float *coef4, float sample_coeff, float eps_coeff, int32_t mode,
+                          float *cur_sample_ws, float *x, ctx_stream_t stream);
+
+/* Unit-test support: one 32x32 tile through the MFMA fragment maps the kernels assume.
+   which 0: f16 32x32x16 (A[32][16], Bt[32][16]); 1: f32 32x32x2 (A[32][2], Bt[32][2]); C[32][32] f32. */
+int32_t ctx_probe_mfma(int32_t which, const void *A, const void *Bt, float *C, ctx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

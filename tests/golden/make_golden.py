@@ -213,5 +213,25 @@ def main():
     print('wrote', len(out), 'arrays;', os.path.getsize(os.path.join(HERE, 'reference_vectors.npz')), 'bytes')
 
 
-if __name__ == '__main__':
+
+
+def make_meshes():
+    """Bundled benchmark meshes (shapes/*.obj of the reference) as arrays: data, not source."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.geometry import load_obj
+    out = {}
+    for name in ['nascar', 'spot_triangulated', 'bunny', 'blub_no_texture', 'sphere', 'env_sphere']:
+        v, f, vt, ft = load_obj(os.path.join(REF, 'shapes', name + '.obj'))
+        out[name + '_v'] = v; out[name + '_f'] = f.astype(np.int32)
+        out[name + '_vt'] = vt; out[name + '_ft'] = ft.astype(np.int32)
+        print(name, v.shape, f.shape, vt.shape, int(ft.min()) if ft.size else None)
+    np.savez_compressed(os.path.join(HERE, 'meshes.npz'), **out)
+    print('meshes.npz', os.path.getsize(os.path.join(HERE, 'meshes.npz')))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'meshes':
+    make_meshes()
+
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+    make_meshes()

@@ -1,0 +1,238 @@
+"""GPU parity: HIP raster / uv / view-weight / texture-field kernels (through the C-ABI) against the
+oracle on the same seeded inputs.  Integer and float32 geometry results must be BIT-EXACT (both sides run
+uncontracted IEEE binary32 in the same order); transcendental paths carry an explicit tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as og, nerf as onerf
+
+pytestmark = pytest.mark.gpu
+
+ZP_THETA = np.float32([1.0471975803375244] * 4 + [1.919862151145935] * 3)       # Zero123PlusDataset (golden meta)
+ZP_PHI = np.deg2rad(np.float32([0, 30, 150, 270, 90, 210, 330])).astype(np.float32)
+
+
+def _scene(meshes, name, B, dy=0.25):
+    v = og.normalize_mesh(meshes[name + '_v'], 0.6, dy)
+    f = meshes[name + '_f'].astype(np.int64)
+    cam = og.get_camera_from_multiple_view(ZP_THETA[:B], ZP_PHI[:B], np.full(B, 1.5, np.float32), dy)
+    proj = og.generate_perspective_projection(np.pi / 3)
+    return np.repeat(v[None], B, 0), f, cam, proj
+
+
+def _uv_attr(meshes, name, F, seed=0):
+    vt, ft = meshes[name + '_vt'], meshes[name + '_ft']
+    if vt.shape[0] and ft.min() >= 0:
+        return vt[ft.astype(np.int64)][None].astype(np.float32)                     # [1,F,3,2]
+    return np.random.default_rng(seed).random((1, F, 3, 2), dtype=np.float32)
+
+
+def test_mfma_lane_maps(dev):
+    """The fragment maps every MFMA kernel relies on, with asymmetric integer data (exact in f16/f32)."""
+    from contexture_nerf_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-4, 5, (32, 16), generator=g).float()
+    B = torch.randint(-4, 5, (32, 16), generator=g).float()
+    C = torch.zeros(32, 32, device=dev)
+    L.check(lib.ctx_probe_mfma(0, L.ptr(A.half().to(dev)), L.ptr(B.half().to(dev)), L.ptr(C), L.stream()))
+    assert torch.equal(C.cpu(), A @ B.T)
+    A2 = torch.randint(-9, 10, (32, 2), generator=g).float()
+    B2 = torch.randint(-9, 10, (32, 2), generator=g).float()
+    L.check(lib.ctx_probe_mfma(1, L.ptr(A2.to(dev)), L.ptr(B2.to(dev)), L.ptr(C), L.stream()))
+    assert torch.equal(C.cpu(), A2 @ B2.T)
+
+
+@pytest.mark.parametrize("name,B,H,W", [("sphere", 2, 64, 64), ("spot_triangulated", 3, 256, 256),
+                                        ("nascar", 7, 200, 200), ("bunny", 1, 97, 131),
+                                        ("blub_no_texture", 2, 320, 320), ("env_sphere", 1, 128, 128)])
+def test_prepare_and_raster_bit_exact(dev, meshes, name, B, H, W):
+    from contexture_nerf_amd import kal
+    verts, f, cam, proj = _scene(meshes, name, B)
+    o_cam, o_img, o_fn = og.prepare_vertices(verts, f, proj, cam)
+    g_cam, g_img, g_fn = kal.render.mesh.prepare_vertices(torch.tensor(verts, device=dev), torch.tensor(f, device=dev),
+                                                          torch.tensor(proj), camera_transform=torch.tensor(cam, device=dev))
+    assert np.array_equal(g_cam.cpu().numpy(), o_cam)
+    assert np.array_equal(g_img.cpu().numpy(), o_img)
+    assert np.array_equal(g_fn.cpu().numpy(), o_fn)
+    uva = _uv_attr(meshes, name, f.shape[0])
+    # reference form: two passes (depth feature, then uv feature)
+    o_d, o_i = og.rasterize(H, W, o_cam[..., 2], o_img, o_cam[..., 2:3])
+    o_uv, o_i2 = og.rasterize(H, W, o_cam[..., 2], o_img, np.repeat(uva, B, 0))
+    assert np.array_equal(o_i, o_i2)
+    g_d, g_i = kal.render.mesh.rasterize(H, W, g_cam[..., 2], g_img, g_cam[..., 2:3])
+    g_uv, g_i2 = kal.render.mesh.rasterize(H, W, g_cam[..., 2], g_img, torch.tensor(uva, device=dev).repeat(B, 1, 1, 1))
+    assert g_i.dtype == torch.int64
+    assert np.array_equal(g_i.cpu().numpy(), o_i), f"{(g_i.cpu().numpy() != o_i).sum()} face ids differ"
+    assert np.array_equal(g_i2.cpu().numpy(), o_i)
+    assert np.array_equal(g_d.cpu().numpy(), o_d)
+    assert np.array_equal(g_uv.cpu().numpy(), o_uv)
+    # fused single pass == both passes + normals gather
+    f_d, f_uv, f_i, f_n = kal.render.mesh.rasterize_fused(H, W, g_cam, g_img, torch.tensor(uva, device=dev), g_fn)
+    assert np.array_equal(f_i.cpu().numpy(), o_i)
+    assert np.array_equal(f_d.cpu().numpy(), o_d)
+    assert np.array_equal(f_uv.cpu().numpy(), o_uv)
+    assert np.array_equal(f_n.cpu().numpy(), og.gather_normals(o_i, o_fn))
+    assert (o_i >= 0).mean() > 0.02
+
+
+def test_raster_edge_cases(dev):
+    """Degenerate (zero-area) faces, exact depth ties (lowest index must win), faces off-screen, 1x1 image."""
+    from contexture_nerf_amd import kal
+    fxy = np.float32([[[-0.5, -0.5], [0.5, -0.5], [0.0, 0.5]],        # face 0
+                      [[-0.5, -0.5], [0.5, -0.5], [0.0, 0.5]],        # face 1 == face 0 (tie)
+                      [[0.2, 0.2], [0.2, 0.2], [0.2, 0.2]],           # degenerate
+                      [[3.0, 3.0], [4.0, 3.0], [3.5, 4.0]],           # off-screen
+                      [[-0.9, 0.1], [-0.1, 0.1], [-0.5, 0.9]]])[None]  # partly overlapping, nearer
+    fz = np.float32([[-2, -2, -2], [-2, -2, -2], [-1, -1, -1], [-1, -1, -1], [-1.5, -1.2, -1.7]])[None]
+    feat = np.random.default_rng(0).random((1, 5, 3, 3), dtype=np.float32)
+    for (H, W) in [(33, 47), (1, 1), (8, 300)]:
+        o, oi = og.rasterize(H, W, fz, fxy, feat)
+        g, gi = kal.render.mesh.rasterize(H, W, torch.tensor(fz, device=dev), torch.tensor(fxy, device=dev),
+                                          torch.tensor(feat, device=dev))
+        assert np.array_equal(gi.cpu().numpy(), oi)
+        assert np.array_equal(g.cpu().numpy(), o)
+    assert 1 not in np.unique(oi)          # tie: face 0 hides its duplicate
+    # all-background view
+    o, oi = og.rasterize(16, 16, fz[:, 3:4], fxy[:, 3:4], feat[:, 3:4])
+    g, gi = kal.render.mesh.rasterize(16, 16, torch.tensor(fz[:, 3:4], device=dev), torch.tensor(fxy[:, 3:4], device=dev),
+                                      torch.tensor(feat[:, 3:4], device=dev))
+    assert (gi.cpu().numpy() == -1).all() and np.array_equal(g.cpu().numpy(), o)
+
+
+def test_normalize_depth(dev, meshes, golden):
+    from contexture_nerf_amd import render
+    d = torch.tensor(golden['depth_raw'], device=dev)
+    out = render.Renderer.normalize_multiple_depth(None, d)
+    assert np.array_equal(out.cpu().numpy(), golden['depth_norm'])          # vs the reference's own output
+    with pytest.raises(AssertionError, match='negative'):
+        render.Renderer.normalize_multiple_depth(None, -d)
+    with pytest.raises(AssertionError, match='empty'):
+        render.Renderer.normalize_multiple_depth(None, torch.zeros_like(d))
+    big = -(torch.rand(3, 300, 301, 1, device=dev) + 0.25)
+    big[:, :50] = 0
+    assert np.array_equal(render.Renderer.normalize_multiple_depth(None, big).cpu().numpy(),
+                          og.normalize_multiple_depth(big.cpu().numpy()))
+
+
+def test_texture_mapping_fwd_bwd(dev):
+    from contexture_nerf_amd import kal
+    g = torch.Generator().manual_seed(0)
+    uv = torch.rand(3, 70, 90, 2, generator=g) * 1.1 - 0.05
+    tex = torch.rand(1, 3, 64, 64, generator=g)
+    for mode in ('bilinear', 'nearest'):
+        o = og.texture_mapping(uv.numpy(), tex.numpy(), mode)
+        out = kal.render.mesh.texture_mapping(uv.to(dev), tex.to(dev).expand(3, -1, -1, -1), mode=mode)
+        assert np.array_equal(out.cpu().numpy(), o)                       # bit-exact float32
+        ref = torch.nn.functional.grid_sample(tex.expand(3, -1, -1, -1), torch.stack([uv[..., 0], 1 - uv[..., 1]], -1) * 2 - 1,
+                                              mode=mode, align_corners=False, padding_mode='border').permute(0, 2, 3, 1)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    # backward (float atomics: order-dependent rounding -> tolerance, stated here: 1e-5 abs on O(10) sums)
+    texd = tex.to(dev).requires_grad_(True)
+    y = kal.render.mesh.texture_mapping(uv.to(dev), texd.expand(3, -1, -1, -1))
+    go = torch.rand(y.shape, generator=g)
+    (y * go.to(dev)).sum().backward()
+    gt = og.texture_mapping_bwd(go.numpy(), uv.numpy(), 64)
+    np.testing.assert_allclose(texd.grad[0].cpu().numpy(), gt, rtol=1e-4, atol=2e-5)
+
+
+def test_view_weights_vs_reference_vectors(dev, golden):
+    from contexture_nerf_amd import view_weights as vw
+    fi = torch.tensor(golden['vw_face_idx'], device=dev)
+    fn = torch.tensor(golden['vw_face_normals'], device=dev)
+    masks = vw.compare_face_normals_between_views(None, fn, fi)
+    assert masks.dtype == torch.bool and masks.shape == fi.shape
+    assert np.array_equal(masks.cpu().numpy(), golden['vw_masks'])          # the reference's own output
+    fvm = vw.create_face_view_map(fi)
+    assert np.array_equal(fvm.cpu().numpy(), golden['vw_face_view_map'])
+    toy = torch.tensor([[[[0, -1], [1, 1]]], [[[1, 0], [-1, 2]]]], device=dev)
+    assert np.array_equal(vw.create_face_view_map(toy).cpu().numpy(), golden['vw_toy_map'])
+
+
+def test_view_weights_full_size(dev, meshes):
+    """B=7 @ 600^2 on nascar: bit-exact masks vs oracle, plus size-independent properties."""
+    from contexture_nerf_amd import kal, view_weights as vw
+    verts, f, cam, proj = _scene(meshes, 'nascar', 7)
+    g_cam, g_img, g_fn = kal.render.mesh.prepare_vertices(torch.tensor(verts, device=dev), torch.tensor(f, device=dev),
+                                                          torch.tensor(proj), camera_transform=torch.tensor(cam, device=dev))
+    _, _, idx, _ = kal.render.mesh.rasterize_fused(600, 600, g_cam, g_img, torch.rand(1, f.shape[0], 3, 2, device=dev))
+    fn = g_fn.permute(0, 2, 1).contiguous()
+    masks = vw.view_weight_masks(idx[:, None], fn)
+    mz, om = og.view_weights(idx.cpu().numpy(), g_fn[..., 2].cpu().numpy())
+    assert np.array_equal(masks[:, 0].cpu().numpy(), om)
+    m = masks[:, 0]
+    assert bool(m[idx < 0].all())                                          # background stays True
+    # every visible face is owned by at least one view; shard-and-reduce (2 "ranks") gives the same masks
+    a, fnz_a = vw.local_max_z(idx[:4, None], fn[:4])
+    b, fnz_b = vw.local_max_z(idx[4:, None], fn[4:])
+    red = torch.maximum(a, b)
+    assert torch.equal(red[torch.isfinite(red)], torch.tensor(mz, device=dev)[torch.isfinite(red)])
+    m2 = torch.cat([vw.masks_from_max_z(idx[:4, None], fnz_a, red), vw.masks_from_max_z(idx[4:, None], fnz_b, red)])
+    assert torch.equal(m2, masks)
+    fvm = vw.create_face_view_map(idx[:, None])
+    assert fvm.shape[0] == int((idx >= 0).sum())
+    assert bool((fvm[1:, 1] >= fvm[:-1, 1]).all())                          # view-major order
+
+
+def test_embed_and_texture_field(dev, golden):
+    from contexture_nerf_amd import run_nerf_helpers as rnh
+    embed, odim = rnh.get_embedder(10)
+    assert odim == 42
+    x = torch.tensor(golden['embed_x'], device=dev)
+    e = embed(x)
+    np.testing.assert_allclose(e.cpu().numpy(), golden['embed_y'], rtol=0, atol=3e-6)    # sin/cos of args up to 512
+    # small net with the reference's stored weights
+    small = rnh.NeRF2D(D=8, W=64, input_ch=42, output_ch=3, skips=[4])
+    sd = {k[len('small_'):]: torch.tensor(golden[k]) for k in golden.files if k.startswith('small_') and k != 'small_y'}
+    small.load_state_dict(sd)
+    small.to(dev)
+    y = small(torch.tensor(golden['embed_y'], device=dev))
+    np.testing.assert_allclose(y.cpu().numpy(), golden['small_y'], rtol=1e-4, atol=2e-5)
+    y2 = small.forward_uv(x)                                                # fused embed
+    np.testing.assert_allclose(y2.cpu().numpy(), golden['small_y'], rtol=1e-4, atol=5e-5)
+    # full-size net: same seed => same init as the reference (init order parity) => same outputs
+    torch.manual_seed(1234)
+    net = rnh.NeRF2D(D=8, W=256, input_ch=42, output_ch=3, skips=[4])
+    assert sum(p.numel() for p in net.parameters()) == 483075
+    net.to(dev)
+    y = net(torch.tensor(golden['embed_y'], device=dev))
+    np.testing.assert_allclose(y.cpu().numpy(), golden['nerf2d_seed1234_y'], rtol=1e-4, atol=2e-5)
+    # texture_map(res) == explicit uv grid path == oracle
+    res = 40
+    tex, raw = net.texture_map(res)
+    uvg = onerf.uv_grid(res)
+    assert np.array_equal(uvg, torch.stack(torch.meshgrid(torch.linspace(0, 1, res), torch.linspace(0, 1, res),
+                                                          indexing='xy'), -1).reshape(-1, 2).numpy())
+    raw_explicit = net.forward_uv(torch.tensor(uvg, device=dev))
+    np.testing.assert_allclose(raw.cpu().numpy(), raw_explicit.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    ws = [l.weight.detach().cpu().numpy() for l in net.pts_linears]
+    bs = [l.bias.detach().cpu().numpy() for l in net.pts_linears]
+    o = onerf.nerf2d_forward(onerf.embed(uvg), ws, bs, net.output_linear.weight.detach().cpu().numpy(),
+                             net.output_linear.bias.detach().cpu().numpy(), dtype=np.float64)
+    np.testing.assert_allclose(raw.cpu().numpy(), o, rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(tex.cpu().numpy(), onerf.texture_from_mlp(o, res), rtol=0, atol=1e-4)
+    assert tex.shape == (1, 3, res, res)
+
+
+def test_rays_and_composite(dev, golden):
+    from contexture_nerf_amd import run_nerf_helpers as rnh
+    ro, rd = rnh.get_rays(6, 8, golden['rays_K'], torch.tensor(golden['rays_c2w'], device=dev))
+    np.testing.assert_allclose(rd.cpu().numpy(), golden['rays_d'], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(ro.cpu().numpy(), golden['rays_o'])
+    no, nd = rnh.ndc_rays(6, 8, 5.0, 1.0, ro, rd)
+    np.testing.assert_allclose(no.cpu().numpy(), golden['ndc_o'], rtol=1e-5, atol=1e-5)
+    s = rnh.sample_pdf(torch.tensor(golden['pdf_bins'], device=dev), torch.tensor(golden['pdf_w'], device=dev), 24, det=True)
+    np.testing.assert_allclose(s.cpu().numpy(), golden['pdf_det'], rtol=1e-5, atol=1e-5)
+    s = rnh.sample_pdf(torch.tensor(golden['pdf_bins'], device=dev), torch.tensor(golden['pdf_w'], device=dev), 24, pytest=True)
+    np.testing.assert_allclose(s.cpu().numpy(), golden['pdf_pytest'], rtol=1e-5, atol=1e-5)
+    g = torch.Generator().manual_seed(2)
+    for (R, S) in [(37, 128), (5, 33), (3, 64), (2, 200)]:
+        raw = torch.randn(R, S, 4, generator=g) * 2
+        z = torch.sort(torch.rand(R, S, generator=g) * 4 + 2, -1).values
+        d = torch.randn(R, 3, generator=g)
+        o = og.raw2outputs(raw.numpy(), z.numpy(), d.numpy(), white_bkgd=True)
+        out = rnh.raw2outputs(raw.to(dev), z.to(dev), d.to(dev), white_bkgd=True)
+        # tolerance: wave-parallel prefix product / sums vs sequential float32 oracle, expf ulp differences
+        for a, b in zip(out, o):
+            np.testing.assert_allclose(a.cpu().numpy(), b, rtol=2e-4, atol=2e-6)
