@@ -1,0 +1,192 @@
+// Flash-style fused attention  O = softmax(Q K^T * scale) V  for the UNet transformer blocks
+// (diffusers Attention / AttnProcessor2_0 under src/stable_diffusion_depth.py:422), head_dim 64, fp16
+// operands, fp32 scores / running max / running sum / output accumulator.
+//
+// 4 waves per workgroup, 32 query rows per wave; K/V tiles of 64 keys staged through LDS and shared
+// by the 4 waves.  Scores are computed TRANSPOSED (S^T = K . Q^T: K rows are the MFMA A operand, Q
+// the B operand) so each lane owns one query column: the softmax row reductions are in-register plus a
+// single cross-half shuffle, and the exponentiated tile, converted to f16 in place, is already the B
+// operand of the second product O^T = V^T . P^T (no LDS round trip for P).  V arrives pre-transposed
+// ([B, heads, 64, Skv_pad], keys contiguous) so its fragment is two 8-byte LDS reads.
+#include "common.h"
+#include "kernels.h"
+#include <math.h>
+
+#define AT_KB 64                // keys per tile
+#define AT_KROW 72              // f16 per K row in LDS (144 B: conflict-free ds_read_b128)
+#define AT_VROW 68              // f16 per V^T row in LDS (136 B: conflict-free ds_read_b64)
+
+
+struct AttnArgs {
+    const f16 *Q, *K, *Vt;
+    f16 *O;
+    int Sq, Skv, Sp, heads;
+    int q_stride, kv_stride, o_stride;
+    float scale_log2e;
+};
+
+__global__ __launch_bounds__(256) void k_attention(AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) f16 Ks[AT_KB * AT_KROW];
+    __shared__ __attribute__((aligned(16))) f16 Vs[64 * AT_VROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = q0 + r;
+    const bool qok = qrow < a.Sq;
+
+    // Q fragments: B operand, lane (r,h) holds Q[q0+r][16*ks + 8h + j]
+    f16x8 qf[4];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const f16 *qp = a.Q + ((size_t)b * a.Sq + (qok ? qrow : 0)) * a.q_stride + hd * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qok ? *(const f16x8 *)(qp + ks * 16) : zero8;
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o[d][q] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const f16 *Kb = a.K + (size_t)b * a.Skv * a.kv_stride + hd * 64;
+    const f16 *Vb = a.Vt + ((size_t)b * a.heads + hd) * 64 * a.Sp;
+    const int ntiles = (a.Skv + AT_KB - 1) / AT_KB;
+    const int srow = tid >> 3, sc = tid & 7;        // staging: 32 rows x 8 chunks per pass
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * AT_KB;
+        __syncthreads();                            // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = srow + 32 * i;
+            f16x8 kv = (k0 + key < a.Skv) ? *(const f16x8 *)(Kb + (size_t)(k0 + key) * a.kv_stride + sc * 8) : zero8;
+            *(f16x8 *)(Ks + key * AT_KROW + sc * 8) = kv;
+            int d = srow + 32 * i;                  // V^T row (feature), 8 keys per chunk; Sp-padded, zero filled
+            f16x8 vv = *(const f16x8 *)(Vb + (size_t)d * a.Sp + k0 + sc * 8);
+            f16x4 lo = {vv[0], vv[1], vv[2], vv[3]}, hi = {vv[4], vv[5], vv[6], vv[7]};
+            *(f16x4 *)(Vs + d * AT_VROW + sc * 8) = lo;
+            *(f16x4 *)(Vs + d * AT_VROW + sc * 8 + 4) = hi;
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T : two 32-key blocks -------------------------------------------------
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s[kb][q] = 0.f;
+            const f16 *kp = Ks + (kb * 32 + r) * AT_KROW + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                f16x8 kf = *(const f16x8 *)(kp + ks * 16);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax over this lane's query column ------------------------------------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int key = k0 + kb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                float v = s[kb][q] * a.scale_log2e;
+                if (key >= a.Skv) v = -INFINITY;
+                s[kb][q] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float m_new = fmaxf(m_run, mx);
+        float alpha = exp2f(m_run - m_new);          // m_run = -inf on the first tile -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float p = exp2f(s[kb][q] - m_new);
+                s[kb][q] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[d][q] *= alpha;
+
+        // ---- O^T += V^T . P^T --------------------------------------------------------------------------
+        // P^T as B operand of k-step st (16 keys) of block kb: elements j = registers 8*st + j, whose key is
+        // 16*st + 8*(j>>2) + 4h + (j&3); the V^T (A operand) element j must be that same key.
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                f16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (f16)s[kb][8 * st + j];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const f16 *vp = Vs + (d * 32 + r) * AT_VROW + kb * 32 + 16 * st + 4 * h;
+                    f16x4 v0 = *(const f16x4 *)(vp);
+                    f16x4 v1 = *(const f16x4 *)(vp + 8);
+                    f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[d], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane = query, registers walk d ------------------------------
+    if (qok) {
+        float inv = 1.0f / l_run;
+        f16 *op = a.O + ((size_t)b * a.Sq + qrow) * a.o_stride + hd * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (f16)(o[d][4 * g + j] * inv);
+                *(f16x4 *)(op + d * 32 + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq, int Skv, int Sp, int heads, int q_stride,
+                       int kv_stride, float scale, f16 *O, int o_stride, hipStream_t s)
+{
+    AttnArgs a;
+    a.Q = Q; a.K = K; a.Vt = Vt; a.O = O; a.Sq = Sq; a.Skv = Skv; a.Sp = Sp; a.heads = heads;
+    a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(k_attention, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ctx_set_error("attention launch failed: %s", hipGetErrorString(e));
+        return CTX_E_LAUNCH;
+    }
+    return CTX_OK;
+}
+
+extern "C" int64_t ctx_attention_ws_bytes(int32_t B, int32_t Skv, int32_t heads)
+{
+    int Sp = cdiv(Skv, AT_KB) * AT_KB;
+    return (int64_t)B * heads * 64 * Sp * 2;
+}
+
+extern "C" int32_t ctx_attention_f16(const void *Q, const void *K, const void *V, int32_t B, int32_t Sq, int32_t Skv,
+                                     int32_t heads, int32_t q_stride, int32_t kv_stride, float scale, void *O,
+                                     int32_t o_stride, void *vt_ws, ctx_stream_t stream)
+{
+    CTX_REQUIRE(Q && K && V && O && vt_ws, "attention: null pointer");
+    CTX_REQUIRE(B > 0 && Sq > 0 && Skv > 0 && heads > 0 && q_stride % 8 == 0 && kv_stride % 8 == 0 && o_stride % 4 == 0 &&
+                    q_stride >= heads * 64 && kv_stride >= heads * 64 && o_stride >= heads * 64,
+                "attention: bad strides/sizes (head_dim is fixed at 64)");
+    int Sp = cdiv(Skv, AT_KB) * AT_KB;
+    hipStream_t s = (hipStream_t)stream;
+    ctx_transpose_v_f16((const f16 *)V, B, Skv, kv_stride, heads, Sp, (f16 *)vt_ws, s);
+    return ctx_attention_core((const f16 *)Q, (const f16 *)K, (const f16 *)vt_ws, B, Sq, Skv, Sp, heads, q_stride, kv_stride,
+                              scale, (f16 *)O, o_stride, s);
+}

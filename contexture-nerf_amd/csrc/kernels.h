@@ -1,0 +1,32 @@
+// Internal (non-ABI) host entry points shared between the translation units of libctxnerf.so.
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+    const f16 *X;
+    const f16 *Wt;
+    const f16 *bias;       // [N] or null (GEGLU: packed/interleaved order)
+    const f16 *rowbias;    // [M/rows_per_batch, N] or null
+    const f16 *residual;   // [M, ldr] or null
+    f16 *out;
+    int M, N, K;
+    int ldc, ldr;
+    int rows_per_batch;
+    int ldrb;              // row stride of rowbias
+    int epi;               // 0 plain, 1 GEGLU (out has N/2 columns)
+    // conv
+    int H, W, Cin, Ho, Wo, stride, ups;
+    int ntm, ntn;
+};
+
+int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s);
+int ctx_gemv_f16(const f16 *x, const f16 *w, const f16 *bias, int Bm, int N, int K, int silu_in, int silu_out, f16 *out, hipStream_t s);
+int ctx_concat_f16(const f16 *a, const f16 *b, int64_t M, int Ca, int Cb, f16 *y, hipStream_t s);
+int ctx_transpose_v_f16(const f16 *v, int B, int S, int ld, int heads, int Sp, f16 *vt, hipStream_t s);
+int ctx_f32_to_f16(const float *x, int64_t n, f16 *y, hipStream_t s);
+int ctx_time_embed_f16(const float *t, int B, int dim, f16 *out, hipStream_t s);
+int ctx_conv_in_f16(const float *x, const f16 *w, const f16 *bias, int B, int Cin, int H, int W, int Cout, f16 *y, hipStream_t s);
+int ctx_conv_out_f16(const f16 *x, const f16 *w, const f16 *bias, int B, int H, int W, int C, int Cout, float *out, hipStream_t s);
+int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq, int Skv, int Sp, int heads, int q_stride,
+                       int kv_stride, float scale, f16 *O, int o_stride, hipStream_t s);
+extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups);

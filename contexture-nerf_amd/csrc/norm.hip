@@ -1,0 +1,417 @@
+// Normalisation / elementwise kernels of the UNet denoiser (NHWC fp16 activations, fp32 statistics).
+// HBM-bound: every access is a 16-byte (8 x f16) vector per lane.
+//   GroupNorm(+SiLU)   diffusers ResnetBlock2D norm1/norm2, Transformer2DModel.norm, conv_norm_out
+//   LayerNorm          BasicTransformerBlock norm1/2/3
+//   GEGLU, channel concat, V transpose, layout converters, timestep embedding, conv_in / conv_out,
+//   CFG + PLMS scheduler step (src/stable_diffusion_depth.py:428-430,514).
+#include "common.h"
+#include "kernels.h"
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm.  Pass 1: grid (NS, B); thread (c8, pl) owns 8 channels, walks pixels pl, pl+PL, ...
+// of its split, keeps per-channel sum/sumsq in registers, folds them into per-group LDS bins once.
+// Pass 2 reduces the NS partials per (b, group) on the fly and applies  (x-mean)*rstd*gamma+beta (+SiLU).
+#define GN_MAX_GROUPS 64
+
+__global__ void k_gn_stats(const f16 *__restrict__ x, int HW, int C, int G, int NS, float *__restrict__ part)
+{
+    __shared__ float s_sum[GN_MAX_GROUPS], s_sq[GN_MAX_GROUPS];
+    const int c8n = C / 8;
+    const int PL = blockDim.x / c8n;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    for (int i = threadIdx.x; i < G; i += blockDim.x) { s_sum[i] = 0.f; s_sq[i] = 0.f; }
+    __syncthreads();
+    const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
+    const int per = (HW + NS - 1) / NS;
+    const int p0 = sp * per, p1 = min(HW, p0 + per);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (pl < PL) {
+        const f16 *base = x + ((size_t)b * HW) * C + c8 * 8;
+        for (int p = p0 + pl; p < p1; p += PL) {
+            f16x8 v = *(const f16x8 *)(base + (size_t)p * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+        }
+        const int cg = C / G;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int g = (c8 * 8 + j) / cg;
+            atomicAdd(&s_sum[g], s[j]);
+            atomicAdd(&s_sq[g], q[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < G; i += blockDim.x) {
+        part[(((size_t)b * NS + sp) * G + i) * 2 + 0] = s_sum[i];
+        part[(((size_t)b * NS + sp) * G + i) * 2 + 1] = s_sq[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, const f16 *__restrict__ gamma,
+                                                  const f16 *__restrict__ beta, int HW, int C, int G, int NS, float eps,
+                                                  int silu, const float *__restrict__ part, f16 *__restrict__ y)
+{
+    __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
+    const int b = blockIdx.y;
+    if (threadIdx.x < G) {
+        float s = 0.f, q = 0.f;
+        for (int k = 0; k < NS; ++k) {
+            s += part[(((size_t)b * NS + k) * G + threadIdx.x) * 2 + 0];
+            q += part[(((size_t)b * NS + k) * G + threadIdx.x) * 2 + 1];
+        }
+        float n = (float)HW * (float)(C / G);
+        float mean = s / n;
+        float var = fmaxf(q / n - mean * mean, 0.f);
+        s_mean[threadIdx.x] = mean;
+        s_rstd[threadIdx.x] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int c8n = C / 8, cg = C / G;
+    const size_t total = (size_t)HW * c8n;
+    const f16 *xb = x + (size_t)b * HW * C;
+    f16 *yb = y + (size_t)b * HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int c8 = (int)(i % c8n);
+        f16x8 v = *(const f16x8 *)(xb + i * 8);
+        f16x8 ga = *(const f16x8 *)(gamma + c8 * 8);
+        f16x8 be = *(const f16x8 *)(beta + c8 * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int g = (c8 * 8 + j) / cg;
+            float f = ((float)v[j] - s_mean[g]) * s_rstd[g] * (float)ga[j] + (float)be[j];
+            if (silu) f = f / (1.0f + __expf(-f));
+            o[j] = (f16)f;
+        }
+        *(f16x8 *)(yb + i * 8) = o;
+    }
+}
+
+extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups) { return (int64_t)B * 64 * groups * 2 * 4; }
+
+extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const void *beta, int32_t B, int32_t HW, int32_t C,
+                                     int32_t groups, float eps, int32_t silu, void *y, void *stats_ws, ctx_stream_t stream)
+{
+    CTX_REQUIRE(x && gamma && beta && y && stats_ws, "groupnorm: null pointer");
+    CTX_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS && C / 8 <= 1024,
+                "groupnorm: unsupported B=%d HW=%d C=%d groups=%d", B, HW, C, groups);
+    hipStream_t s = (hipStream_t)stream;
+    int c8n = C / 8;
+    int PL = c8n >= 256 ? 1024 / c8n : 256 / c8n;
+    if (PL < 1) PL = 1;
+    int threads = c8n * PL;
+    int NS = min(64, max(1, HW / (PL * 4)));
+    hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), 0, s, (const f16 *)x, HW, C, groups, NS, (float *)stats_ws);
+    size_t total = (size_t)HW * c8n;
+    int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), 0, s, (const f16 *)x, (const f16 *)gamma, (const f16 *)beta, HW, C,
+                       groups, NS, eps, silu, (const float *)stats_ws, (f16 *)y);
+    CTX_CHECK_LAUNCH("groupnorm");
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wave per row, up to 4 x 16-byte chunks per lane (C <= 2048).
+__global__ __launch_bounds__(256) void k_layernorm(const f16 *__restrict__ x, const f16 *__restrict__ gamma,
+                                                   const f16 *__restrict__ beta, int64_t rows, int C, float eps,
+                                                   f16 *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int c8n = C / 8;
+    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; row < rows; row += ((int64_t)gridDim.x * 256) >> 6) {
+        const f16 *xr = x + row * C;
+        f16x8 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int c8 = lane + 64 * k;
+            if (c8 < c8n) {
+                v[k] = *(const f16x8 *)(xr + c8 * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += (float)v[k][j];
+            }
+        }
+        float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int c8 = lane + 64 * k;
+            if (c8 < c8n) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float d = (float)v[k][j] - mean; q += d * d; }
+            }
+        }
+        float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        f16 *yr = y + row * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int c8 = lane + 64 * k;
+            if (c8 < c8n) {
+                f16x8 ga = *(const f16x8 *)(gamma + c8 * 8);
+                f16x8 be = *(const f16x8 *)(beta + c8 * 8);
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)v[k][j] - mean) * rstd * (float)ga[j] + (float)be[j]);
+                *(f16x8 *)(yr + c8 * 8) = o;
+            }
+        }
+    }
+}
+
+extern "C" int32_t ctx_layernorm_f16(const void *x, const void *gamma, const void *beta, int64_t rows, int32_t C, float eps,
+                                     void *y, ctx_stream_t stream)
+{
+    CTX_REQUIRE(x && gamma && beta && y && rows > 0 && C % 8 == 0 && C <= 2048, "layernorm: unsupported rows=%lld C=%d", (long long)rows, C);
+    int64_t nb = cdiv64(rows, 4);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const f16 *)x, (const f16 *)gamma,
+                       (const f16 *)beta, rows, C, eps, (f16 *)y);
+    CTX_CHECK_LAUNCH("layernorm");
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_geglu(const f16 *__restrict__ h, int64_t M, int C4, f16 *__restrict__ y)
+{
+    const int c8n = C4 / 8;
+    const int64_t total = M * c8n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t m = i / c8n;
+        int c8 = (int)(i % c8n);
+        f16x8 a = *(const f16x8 *)(h + m * 2 * C4 + c8 * 8);
+        f16x8 g = *(const f16x8 *)(h + m * 2 * C4 + C4 + c8 * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float gf = (float)g[j];
+            o[j] = (f16)((float)a[j] * (0.5f * gf * (1.0f + erff(gf * 0.70710678118654752f))));
+        }
+        *(f16x8 *)(y + m * C4 + c8 * 8) = o;
+    }
+}
+
+extern "C" int32_t ctx_geglu_f16(const void *h, int64_t M, int32_t C4, void *y, ctx_stream_t stream)
+{
+    CTX_REQUIRE(h && y && M > 0 && C4 % 8 == 0, "geglu: bad args");
+    int64_t nb = cdiv64(M * (C4 / 8), 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_geglu, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const f16 *)h, M, C4, (f16 *)y);
+    CTX_CHECK_LAUNCH("geglu");
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel concat (NHWC): y[m, :Ca] = a[m], y[m, Ca:] = b[m].
+__global__ __launch_bounds__(256) void k_concat(const f16 *__restrict__ a, const f16 *__restrict__ b, int64_t M, int Ca,
+                                                int Cb, f16 *__restrict__ y)
+{
+    const int n8 = (Ca + Cb) / 8, a8 = Ca / 8;
+    const int64_t total = M * n8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t m = i / n8;
+        int c8 = (int)(i % n8);
+        f16x8 v = c8 < a8 ? *(const f16x8 *)(a + m * Ca + c8 * 8) : *(const f16x8 *)(b + m * Cb + (c8 - a8) * 8);
+        *(f16x8 *)(y + i * 8) = v;
+    }
+}
+
+int ctx_concat_f16(const f16 *a, const f16 *b, int64_t M, int Ca, int Cb, f16 *y, hipStream_t s)
+{
+    int64_t nb = cdiv64(M * ((Ca + Cb) / 8), 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_concat, dim3((unsigned)nb), dim3(256), 0, s, a, b, M, Ca, Cb, y);
+    return CTX_OK;
+}
+
+// V [B, S, ld] (head slice at column h*64) -> Vt [B, heads, 64, Sp] (keys contiguous, zero padded to Sp).
+__global__ __launch_bounds__(256) void k_transpose_v(const f16 *__restrict__ v, int S, int ld, int heads, int Sp,
+                                                     f16 *__restrict__ vt)
+{
+    __shared__ f16 tile[64][66];
+    const int b = blockIdx.z, hd = blockIdx.y, s0 = blockIdx.x * 64;
+    // load 64 keys x 64 d, 16 B per lane: thread t -> key t/8 + 32*i, chunk t%8
+    for (int i = 0; i < 2; ++i) {
+        int key = (threadIdx.x >> 3) + 32 * i, c = threadIdx.x & 7;
+        f16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (s0 + key < S) val = *(const f16x8 *)(v + ((size_t)b * S + s0 + key) * ld + hd * 64 + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[key][c * 8 + j] = val[j];
+    }
+    __syncthreads();
+    for (int i = 0; i < 2; ++i) {
+        int d = (threadIdx.x >> 3) + 32 * i, c = threadIdx.x & 7;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = tile[c * 8 + j][d];
+        if (s0 + c * 8 < Sp) *(f16x8 *)(vt + (((size_t)b * heads + hd) * 64 + d) * Sp + s0 + c * 8) = o;
+    }
+}
+
+int ctx_transpose_v_f16(const f16 *v, int B, int S, int ld, int heads, int Sp, f16 *vt, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_transpose_v, dim3(cdiv(Sp, 64), heads, B), dim3(256), 0, s, v, S, ld, heads, Sp, vt);
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 -> f16 row-major copy (context embeddings).
+__global__ __launch_bounds__(256) void k_f32_to_f16(const float *__restrict__ x, int64_t n, f16 *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (f16)x[i];
+}
+int ctx_f32_to_f16(const float *x, int64_t n, f16 *y, hipStream_t s)
+{
+    int64_t nb = cdiv64(n, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_f32_to_f16, dim3((unsigned)nb), dim3(256), 0, s, x, n, y);
+    return CTX_OK;
+}
+
+// Sinusoidal timestep embedding, diffusers get_timestep_embedding(flip_sin_to_cos=True, freq_shift=0):
+// emb[b] = [cos(t*f_0..f_{h-1}), sin(t*f_0..)] with f_i = exp(-ln(10000) * i / h), h = dim/2.
+__global__ void k_time_embed(const float *__restrict__ t, int B, int dim, f16 *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int half = dim / 2;
+    if (i >= half) return;
+    float fr = expf(-9.210340371976184f * (float)i / (float)half);
+    float a = t[0] * fr;
+    float c = cosf(a), sn = sinf(a);
+    for (int b = 0; b < B; ++b) {
+        out[(size_t)b * dim + i] = (f16)c;
+        out[(size_t)b * dim + half + i] = (f16)sn;
+    }
+}
+int ctx_time_embed_f16(const float *t, int B, int dim, f16 *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_time_embed, dim3(cdiv(dim / 2, 64)), dim3(64), 0, s, t, B, dim, out);
+    return CTX_OK;
+}
+
+// conv_in: sample [B,Cin,H,W] f32 NCHW (Cin <= 8) -> y [B,H,W,Cout] f16, 3x3 pad 1.  w packed [Cout][3][3][8] f16.
+// Tiny (0.5 GFLOP at 96^2): one thread per (pixel, 8 output channels).
+__global__ __launch_bounds__(256) void k_conv_in(const float *__restrict__ x, const f16 *__restrict__ w,
+                                                 const f16 *__restrict__ bias, int B, int Cin, int H, int W, int Cout,
+                                                 f16 *__restrict__ y)
+{
+    const int o8n = Cout / 8;
+    const int64_t total = (int64_t)B * H * W * o8n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int o8 = (int)(i % o8n);
+        int64_t pix = i / o8n;
+        int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
+        int oy = p / W, ox = p % W;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (float)bias[o8 * 8 + j];
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                int iy = oy + ky - 1, ix = ox + kx - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                for (int c = 0; c < Cin; ++c) {
+                    float xv = (float)(f16)x[(((size_t)b * Cin + c) * H + iy) * W + ix];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += xv * (float)w[(((size_t)(o8 * 8 + j) * 3 + ky) * 3 + kx) * 8 + c];
+                }
+            }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)acc[j];
+        *(f16x8 *)(y + pix * Cout + o8 * 8) = o;
+    }
+}
+int ctx_conv_in_f16(const float *x, const f16 *w, const f16 *bias, int B, int Cin, int H, int W, int Cout, f16 *y, hipStream_t s)
+{
+    int64_t nb = cdiv64((int64_t)B * H * W * (Cout / 8), 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_conv_in, dim3((unsigned)nb), dim3(256), 0, s, x, w, bias, B, Cin, H, W, Cout, y);
+    return CTX_OK;
+}
+
+// conv_out: x [B,H,W,C] f16 (already GN+SiLU'd) -> out [B,Cout,H,W] f32 NCHW, Cout <= 4, 3x3 pad 1.
+// w packed [Cout][3][3][C] f16.  One wave per output pixel: lanes split C in 16-byte chunks.
+__global__ __launch_bounds__(256) void k_conv_out(const f16 *__restrict__ x, const f16 *__restrict__ w,
+                                                  const f16 *__restrict__ bias, int B, int H, int W, int C, int Cout,
+                                                  float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t npix = (int64_t)B * H * W;
+    for (int64_t pix = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; pix < npix; pix += ((int64_t)gridDim.x * 256) >> 6) {
+        int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
+        int oy = p / W, ox = p % W;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int tap = 0; tap < 9; ++tap) {
+            int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const f16 *xr = x + (((size_t)b * H + iy) * W + ix) * C;
+            for (int c = lane * 8; c < C; c += 512) {
+                f16x8 xv = *(const f16x8 *)(xr + c);
+                for (int o = 0; o < Cout; ++o) {
+                    f16x8 wv = *(const f16x8 *)(w + ((size_t)o * 9 + tap) * C + c);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[o] += (float)xv[j] * (float)wv[j];
+                }
+            }
+        }
+        for (int o = 0; o < Cout; ++o) {
+            float v = wave_sum(acc[o]);
+            if (lane == 0) out[(((size_t)b * Cout + o) * H + oy) * W + ox] = v + (float)bias[o];
+        }
+    }
+}
+int ctx_conv_out_f16(const f16 *x, const f16 *w, const f16 *bias, int B, int H, int W, int C, int Cout, float *out, hipStream_t s)
+{
+    int64_t nb = cdiv64((int64_t)B * H * W, 4);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_conv_out, dim3((unsigned)nb), dim3(256), 0, s, x, w, bias, B, H, W, C, Cout, out);
+    return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFG combine + PNDM/PLMS linear-multistep update, one pass over the latent.
+__global__ __launch_bounds__(256) void k_cfg_plms(const float *__restrict__ eps_pair, int64_t n, float guidance,
+                                                  float *__restrict__ ets, int head, float c0, float c1, float c2,
+                                                  float c3, float sample_coeff, float eps_coeff, int mode,
+                                                  float *__restrict__ cur, float *__restrict__ x)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float eu = eps_pair[i], et = eps_pair[n + i];
+        float e = eu + guidance * (et - eu);
+        float xs;
+        float comb;
+        if (mode == 1) {
+            // second evaluation of the first PLMS step: average with the stored epsilon, restart from cur_sample
+            comb = (e + ets[(size_t)head * n + i]) / 2.0f;
+            xs = cur[i];
+        } else {
+            ets[(size_t)head * n + i] = e;
+            float e1 = ets[(size_t)((head + 3) & 3) * n + i];
+            float e2 = ets[(size_t)((head + 2) & 3) * n + i];
+            float e3 = ets[(size_t)((head + 1) & 3) * n + i];
+            comb = c0 * e;
+            if (c1 != 0.f) comb += c1 * e1;
+            if (c2 != 0.f) comb += c2 * e2;
+            if (c3 != 0.f) comb += c3 * e3;
+            xs = x[i];
+            if (mode == 2) cur[i] = xs;      // first step: remember cur_sample
+        }
+        x[i] = sample_coeff * xs - eps_coeff * comb;
+    }
+}
+
+extern "C" int32_t ctx_cfg_plms_step(const float *eps_pair, int64_t n, float guidance, float *ets, int32_t head,
+                                     const float *coef4, float sample_coeff, float eps_coeff, int32_t mode,
+                                     float *cur_sample_ws, float *x, ctx_stream_t stream)
+{
+    CTX_REQUIRE(eps_pair && ets && coef4 && x && n > 0 && head >= 0 && head < 4, "cfg_plms_step: bad args");
+    CTX_REQUIRE(mode == 0 || cur_sample_ws, "cfg_plms_step: mode %d needs cur_sample_ws", mode);
+    int64_t nb = cdiv64(n, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_cfg_plms, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, eps_pair, n, guidance, ets, head,
+                       coef4[0], coef4[1], coef4[2], coef4[3], sample_coeff, eps_coeff, mode, cur_sample_ws, x);
+    CTX_CHECK_LAUNCH("cfg_plms_step");
+    return CTX_OK;
+}

@@ -1,0 +1,547 @@
+// UNet denoise engine: the SD2-depth `UNet2DConditionModel` graph (diffusers 0.27.2 naming) executed
+// as a fixed sequence of hand-written gfx950 kernels on one HIP stream.  Replaces
+//   self.unet(latent_model_input_depth, t, encoder_hidden_states=text_embeddings)['sample']
+// at src/stable_diffusion_depth.py:422-423.
+//
+// Memory: one fp16 weight blob (caller-allocated, filled by ctx_unet_set_param from fp32 diffusers-layout
+// tensors: conv weights repacked to [Cout][ky][kx][Cin], q/k/v fused, GEGLU rows interleaved so the gate
+// lives in the same lane as its value, all time_emb_proj layers concatenated into one GEMV) and one
+// workspace arena (bump allocator with mark/release; sized by a dry run of the same code path).
+// Activations are NHWC fp16; statistics, softmax and accumulators are fp32.
+#include "common.h"
+#include "kernels.h"
+#include <string>
+#include <vector>
+#include <string.h>
+
+enum PackKind { PK_COPY = 0, PK_CONV3 = 1, PK_CONVIN = 2, PK_GEGLU_W = 3, PK_GEGLU_B = 4 };
+
+struct Param {
+    std::string name;
+    int ndim;
+    int64_t shape[4];
+    int kind;
+    size_t dst;      // element offset into the fp16 weight blob
+    int a, b;        // kind-specific dims
+};
+
+struct ResP {
+    int cin, cout;
+    size_t n1g, n1b, c1w, c1b, n2g, n2b, c2w, c2b, scw, scb;
+    int temb_row;
+};
+struct TrP {
+    int C, heads;
+    size_t ng, nb, piw, pib, l1g, l1b, qkv, o1w, o1b, l2g, l2b, q2, kv2, o2w, o2b, l3g, l3b, f1w, f1b, f2w, f2b, pow_, pob;
+};
+struct LevelP {
+    std::vector<ResP> res;
+    std::vector<TrP> tr;
+    bool has_attn = false, has_sampler = false;
+    size_t sw = 0, sb = 0;
+    int sc = 0;
+};
+
+struct ctx_unet {
+    ctx_unet_config_t cfg;
+    std::vector<Param> params;
+    size_t wtop = 0;           // elements
+    // parameter offsets
+    size_t ciw, cib, t1w, t1b, t2w, t2b, tpw, tpb, cng, cnb, cow, cob;
+    int temb_dim = 0, temb_rows = 0;
+    std::vector<LevelP> down, up;
+    LevelP mid;
+    // bound memory
+    f16 *W = nullptr;
+    char *ws = nullptr;
+    size_t ws_cap = 0;
+    // arena state
+    size_t top = 0, peak = 0;
+    bool dry = false;
+    hipStream_t s = nullptr;
+    int rc = 0;
+    // stats
+    int64_t launches[3] = {0, 0, 0};
+    double flops[3] = {0, 0, 0};
+
+    size_t walloc(size_t n) { size_t o = wtop; wtop += (n + 127) / 128 * 128; return o; }
+    size_t add(const std::string &name, std::vector<int64_t> shp, int kind, size_t dst, int a = 0, int b = 0)
+    {
+        Param p; p.name = name; p.ndim = (int)shp.size(); p.kind = kind; p.dst = dst; p.a = a; p.b = b;
+        for (int i = 0; i < 4; ++i) p.shape[i] = i < p.ndim ? shp[i] : 1;
+        params.push_back(p);
+        return dst;
+    }
+    size_t vec(const std::string &name, int n) { return add(name, {n}, PK_COPY, walloc(n)); }
+    size_t lin(const std::string &name, int out, int in) { return add(name, {out, in}, PK_COPY, walloc((size_t)out * in)); }
+
+    void *alloc(size_t bytes)
+    {
+        size_t o = (top + 255) / 256 * 256;
+        top = o + bytes;
+        if (top > peak) peak = top;
+        if (!dry && top > ws_cap) { rc = CTX_E_STATE; ctx_set_error("unet: workspace too small (%zu > %zu)", top, ws_cap); return ws; }
+        return dry ? nullptr : (void *)(ws + o);
+    }
+    f16 *allocH(size_t n) { return (f16 *)alloc(n * 2); }
+};
+
+// ------------------------------------------------------------------------------------------------
+static void add_resnet(ctx_unet *u, const std::string &p, int cin, int cout, ResP &r)
+{
+    r.cin = cin; r.cout = cout;
+    r.n1g = u->vec(p + ".norm1.weight", cin); r.n1b = u->vec(p + ".norm1.bias", cin);
+    r.c1w = u->add(p + ".conv1.weight", {cout, cin, 3, 3}, PK_CONV3, u->walloc((size_t)cout * cin * 9), cout, cin);
+    r.c1b = u->vec(p + ".conv1.bias", cout);
+    // time_emb_proj rows live in the concatenated [sum Cout, temb] matrix
+    r.temb_row = u->temb_rows;
+    u->add(p + ".time_emb_proj.weight", {cout, u->temb_dim}, PK_COPY, u->tpw + (size_t)u->temb_rows * u->temb_dim);
+    u->add(p + ".time_emb_proj.bias", {cout}, PK_COPY, u->tpb + u->temb_rows);
+    u->temb_rows += cout;
+    r.n2g = u->vec(p + ".norm2.weight", cout); r.n2b = u->vec(p + ".norm2.bias", cout);
+    r.c2w = u->add(p + ".conv2.weight", {cout, cout, 3, 3}, PK_CONV3, u->walloc((size_t)cout * cout * 9), cout, cout);
+    r.c2b = u->vec(p + ".conv2.bias", cout);
+    if (cin != cout) {
+        r.scw = u->add(p + ".conv_shortcut.weight", {cout, cin, 1, 1}, PK_COPY, u->walloc((size_t)cout * cin));
+        r.scb = u->vec(p + ".conv_shortcut.bias", cout);
+    } else r.scw = r.scb = 0;
+}
+
+static void add_transformer(ctx_unet *u, const std::string &p, int C, int heads, TrP &t)
+{
+    int cd = u->cfg.cross_attention_dim;
+    t.C = C; t.heads = heads;
+    t.ng = u->vec(p + ".norm.weight", C); t.nb = u->vec(p + ".norm.bias", C);
+    t.piw = u->lin(p + ".proj_in.weight", C, C); t.pib = u->vec(p + ".proj_in.bias", C);
+    std::string b = p + ".transformer_blocks.0";
+    t.l1g = u->vec(b + ".norm1.weight", C); t.l1b = u->vec(b + ".norm1.bias", C);
+    t.qkv = u->walloc((size_t)3 * C * C);
+    u->add(b + ".attn1.to_q.weight", {C, C}, PK_COPY, t.qkv);
+    u->add(b + ".attn1.to_k.weight", {C, C}, PK_COPY, t.qkv + (size_t)C * C);
+    u->add(b + ".attn1.to_v.weight", {C, C}, PK_COPY, t.qkv + (size_t)2 * C * C);
+    t.o1w = u->lin(b + ".attn1.to_out.0.weight", C, C); t.o1b = u->vec(b + ".attn1.to_out.0.bias", C);
+    t.l2g = u->vec(b + ".norm2.weight", C); t.l2b = u->vec(b + ".norm2.bias", C);
+    t.q2 = u->lin(b + ".attn2.to_q.weight", C, C);
+    t.kv2 = u->walloc((size_t)2 * C * cd);
+    u->add(b + ".attn2.to_k.weight", {C, cd}, PK_COPY, t.kv2);
+    u->add(b + ".attn2.to_v.weight", {C, cd}, PK_COPY, t.kv2 + (size_t)C * cd);
+    t.o2w = u->lin(b + ".attn2.to_out.0.weight", C, C); t.o2b = u->vec(b + ".attn2.to_out.0.bias", C);
+    t.l3g = u->vec(b + ".norm3.weight", C); t.l3b = u->vec(b + ".norm3.bias", C);
+    t.f1w = u->add(b + ".ff.net.0.proj.weight", {8 * C, C}, PK_GEGLU_W, u->walloc((size_t)8 * C * C), 4 * C, C);
+    t.f1b = u->add(b + ".ff.net.0.proj.bias", {8 * C}, PK_GEGLU_B, u->walloc((size_t)8 * C), 4 * C, 0);
+    t.f2w = u->lin(b + ".ff.net.2.weight", C, 4 * C); t.f2b = u->vec(b + ".ff.net.2.bias", C);
+    t.pow_ = u->lin(p + ".proj_out.weight", C, C); t.pob = u->vec(p + ".proj_out.bias", C);
+}
+
+extern "C" ctx_unet_t *ctx_unet_create(const ctx_unet_config_t *cfg)
+{
+    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->in_channels > 8 || cfg->out_channels > 4 ||
+        cfg->groups > 64 || cfg->layers_per_block < 1 || cfg->layers_per_block > 4 || cfg->cross_attention_dim % 64) {
+        ctx_set_error("unet_create: unsupported config");
+        return nullptr;
+    }
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->block_out_channels[i] % 64 || cfg->block_out_channels[i] % cfg->groups || cfg->heads[i] * 64 != cfg->block_out_channels[i]) {
+            ctx_set_error("unet_create: level %d: channels %d must be a multiple of 64 and of groups, with head_dim 64 (heads=%d)",
+                          i, cfg->block_out_channels[i], cfg->heads[i]);
+            return nullptr;
+        }
+    ctx_unet *u = new ctx_unet();
+    u->cfg = *cfg;
+    const int n = cfg->n_levels, lpb = cfg->layers_per_block;
+    const int *ch = cfg->block_out_channels;
+    u->temb_dim = ch[0] * 4;
+    // total time_emb_proj rows
+    int rows = 0;
+    for (int i = 0; i < n; ++i) rows += lpb * ch[i];
+    rows += 2 * ch[n - 1];
+    for (int i = 0; i < n; ++i) rows += (lpb + 1) * ch[n - 1 - i];
+    u->tpw = u->walloc((size_t)rows * u->temb_dim);
+    u->tpb = u->walloc(rows);
+
+    u->ciw = u->add("conv_in.weight", {ch[0], cfg->in_channels, 3, 3}, PK_CONVIN, u->walloc((size_t)ch[0] * 72), ch[0], cfg->in_channels);
+    u->cib = u->vec("conv_in.bias", ch[0]);
+    u->t1w = u->lin("time_embedding.linear_1.weight", u->temb_dim, ch[0]); u->t1b = u->vec("time_embedding.linear_1.bias", u->temb_dim);
+    u->t2w = u->lin("time_embedding.linear_2.weight", u->temb_dim, u->temb_dim); u->t2b = u->vec("time_embedding.linear_2.bias", u->temb_dim);
+    u->down.resize(n);
+    int out = ch[0];
+    for (int i = 0; i < n; ++i) {
+        LevelP &L = u->down[i];
+        int cin = out; out = ch[i];
+        std::string p = "down_blocks." + std::to_string(i);
+        L.res.resize(lpb);
+        for (int j = 0; j < lpb; ++j) add_resnet(u, p + ".resnets." + std::to_string(j), j == 0 ? cin : out, out, L.res[j]);
+        L.has_attn = cfg->down_attn[i] != 0;
+        if (L.has_attn) {
+            L.tr.resize(lpb);
+            for (int j = 0; j < lpb; ++j) add_transformer(u, p + ".attentions." + std::to_string(j), out, cfg->heads[i], L.tr[j]);
+        }
+        if (i != n - 1) {
+            L.has_sampler = true; L.sc = out;
+            L.sw = u->add(p + ".downsamplers.0.conv.weight", {out, out, 3, 3}, PK_CONV3, u->walloc((size_t)out * out * 9), out, out);
+            L.sb = u->vec(p + ".downsamplers.0.conv.bias", out);
+        }
+    }
+    {
+        LevelP &L = u->mid;
+        L.res.resize(2); L.tr.resize(1); L.has_attn = true;
+        add_resnet(u, "mid_block.resnets.0", ch[n - 1], ch[n - 1], L.res[0]);
+        add_transformer(u, "mid_block.attentions.0", ch[n - 1], cfg->heads[n - 1], L.tr[0]);
+        add_resnet(u, "mid_block.resnets.1", ch[n - 1], ch[n - 1], L.res[1]);
+    }
+    u->up.resize(n);
+    out = ch[n - 1];
+    for (int i = 0; i < n; ++i) {
+        LevelP &L = u->up[i];
+        int prev = out; out = ch[n - 1 - i];
+        int inp = ch[n - 1 - (i + 1 < n ? i + 1 : n - 1)];
+        std::string p = "up_blocks." + std::to_string(i);
+        L.res.resize(lpb + 1);
+        for (int j = 0; j <= lpb; ++j) {
+            int skip = j == lpb ? inp : out;
+            int rin = j == 0 ? prev : out;
+            add_resnet(u, p + ".resnets." + std::to_string(j), rin + skip, out, L.res[j]);
+        }
+        L.has_attn = cfg->up_attn[i] != 0;
+        if (L.has_attn) {
+            L.tr.resize(lpb + 1);
+            for (int j = 0; j <= lpb; ++j) add_transformer(u, p + ".attentions." + std::to_string(j), out, cfg->heads[n - 1 - i], L.tr[j]);
+        }
+        if (i != n - 1) {
+            L.has_sampler = true; L.sc = out;
+            L.sw = u->add(p + ".upsamplers.0.conv.weight", {out, out, 3, 3}, PK_CONV3, u->walloc((size_t)out * out * 9), out, out);
+            L.sb = u->vec(p + ".upsamplers.0.conv.bias", out);
+        }
+    }
+    u->cng = u->vec("conv_norm_out.weight", ch[0]); u->cnb = u->vec("conv_norm_out.bias", ch[0]);
+    u->cow = u->add("conv_out.weight", {cfg->out_channels, ch[0], 3, 3}, PK_CONV3, u->walloc((size_t)cfg->out_channels * ch[0] * 9), cfg->out_channels, ch[0]);
+    u->cob = u->vec("conv_out.bias", cfg->out_channels);
+    if (u->temb_rows != rows) {
+        ctx_set_error("unet_create: internal temb row count mismatch %d != %d", u->temb_rows, rows);
+        delete u;
+        return nullptr;
+    }
+    return u;
+}
+
+extern "C" void ctx_unet_destroy(ctx_unet_t *u) { delete u; }
+extern "C" int32_t ctx_unet_param_count(const ctx_unet_t *u) { return u ? (int32_t)u->params.size() : 0; }
+extern "C" const char *ctx_unet_param_name(const ctx_unet_t *u, int32_t i)
+{
+    return (u && i >= 0 && i < (int)u->params.size()) ? u->params[i].name.c_str() : "";
+}
+extern "C" int32_t ctx_unet_param_shape(const ctx_unet_t *u, int32_t i, int64_t shape4[4])
+{
+    if (!u || i < 0 || i >= (int)u->params.size()) return 0;
+    for (int k = 0; k < 4; ++k) shape4[k] = u->params[i].shape[k];
+    return u->params[i].ndim;
+}
+extern "C" int64_t ctx_unet_weight_bytes(const ctx_unet_t *u) { return u ? (int64_t)u->wtop * 2 + 256 : 0; }
+
+extern "C" int32_t ctx_unet_bind(ctx_unet_t *u, void *weights, void *workspace, int64_t workspace_bytes)
+{
+    CTX_REQUIRE(u && weights && workspace && workspace_bytes > 0, "unet_bind: bad args");
+    CTX_REQUIRE(((uintptr_t)weights & 255) == 0 && ((uintptr_t)workspace & 255) == 0, "unet_bind: blobs must be 256-byte aligned");
+    u->W = (f16 *)weights; u->ws = (char *)workspace; u->ws_cap = (size_t)workspace_bytes;
+    return CTX_OK;
+}
+
+// ---- parameter repack kernels ----------------------------------------------------------------------
+__global__ void k_pack_copy(const float *__restrict__ s, int64_t n, f16 *__restrict__ d)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = (f16)s[i];
+}
+// [Cout,Cin,3,3] -> [Cout][3][3][Cinp] (Cinp = Cin, or 8 for conv_in)
+__global__ void k_pack_conv3(const float *__restrict__ s, int Cout, int Cin, int Cinp, f16 *__restrict__ d)
+{
+    int64_t n = (int64_t)Cout * 9 * Cinp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int c = (int)(i % Cinp);
+        int tap = (int)((i / Cinp) % 9);
+        int o = (int)(i / ((int64_t)Cinp * 9));
+        d[i] = c < Cin ? (f16)s[((int64_t)o * Cin + c) * 9 + tap] : (f16)0.f;
+    }
+}
+// GEGLU rows: packed row p (of 2*C4) <- source row  (w<32 ? blk*32+w : C4 + blk*32 + w-32), blk=p/64, w=p%64
+__global__ void k_pack_geglu(const float *__restrict__ s, int C4, int K, f16 *__restrict__ d)
+{
+    int64_t n = (int64_t)2 * C4 * (K > 0 ? K : 1);
+    int kk = K > 0 ? K : 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int k = (int)(i % kk);
+        int p = (int)(i / kk);
+        int blk = p / 64, w = p % 64;
+        int src = w < 32 ? blk * 32 + w : C4 + blk * 32 + (w - 32);
+        d[i] = (f16)s[(int64_t)src * kk + k];
+    }
+}
+
+extern "C" int32_t ctx_unet_set_param(ctx_unet_t *u, int32_t i, const float *src, ctx_stream_t stream)
+{
+    CTX_REQUIRE(u && u->W && src && i >= 0 && i < (int)u->params.size(), "unet_set_param: bad args / not bound");
+    const Param &p = u->params[i];
+    hipStream_t s = (hipStream_t)stream;
+    int64_t n = 1;
+    for (int k = 0; k < p.ndim; ++k) n *= p.shape[k];
+    f16 *d = u->W + p.dst;
+    int64_t nbk = cdiv64(n, 256);
+    unsigned nb = (unsigned)(nbk > 4096 ? 4096 : nbk);
+    switch (p.kind) {
+    case PK_COPY: hipLaunchKernelGGL(k_pack_copy, dim3(nb), dim3(256), 0, s, src, n, d); break;
+    case PK_CONV3: hipLaunchKernelGGL(k_pack_conv3, dim3(nb), dim3(256), 0, s, src, p.a, p.b, p.b, d); break;
+    case PK_CONVIN: hipLaunchKernelGGL(k_pack_conv3, dim3(nb), dim3(256), 0, s, src, p.a, p.b, 8, d); break;
+    case PK_GEGLU_W: hipLaunchKernelGGL(k_pack_geglu, dim3(nb), dim3(256), 0, s, src, p.a, p.b, d); break;
+    case PK_GEGLU_B: hipLaunchKernelGGL(k_pack_geglu, dim3(nb), dim3(256), 0, s, src, p.a, 0, d); break;
+    }
+    CTX_CHECK_LAUNCH("unet_set_param");
+    return CTX_OK;
+}
+
+// ---- op wrappers (skip launches on a dry run, keep accounting identical) ---------------------------------
+static void note(ctx_unet *u, int klass, double fl, int n = 1) { u->launches[klass] += n; u->flops[klass] += fl; }
+#define RUN(expr) do { if (!u->dry && u->rc == 0) { int r__ = (expr); if (r__ != 0) u->rc = r__; } } while (0)
+
+static void op_gemm(ctx_unet *u, const f16 *X, size_t w, size_t bias, bool has_bias, const f16 *res, int M, int N, int K, f16 *out,
+                    int epi = 0)
+{
+    GemmArgs a = {};
+    a.X = X; a.Wt = u->W + w; a.bias = has_bias ? u->W + bias : nullptr; a.residual = res; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.ldc = epi == 1 ? N / 2 : N; a.ldr = N; a.rows_per_batch = 1; a.ldrb = N; a.epi = epi;
+    note(u, 0, 2.0 * M * N * K);
+    RUN(ctx_gemm_dispatch(a, false, u->s));
+}
+static void op_conv(ctx_unet *u, const f16 *x, size_t w, size_t bias, const f16 *rowbias, int ldrb, const f16 *res, int B, int H,
+                    int W, int Cin, int Cout, int stride, int ups, f16 *out)
+{
+    GemmArgs a = {};
+    int Hv = H << ups, Wv = W << ups;
+    a.Ho = (Hv - 1) / stride + 1; a.Wo = (Wv - 1) / stride + 1;
+    a.X = x; a.Wt = u->W + w; a.bias = u->W + bias; a.rowbias = rowbias; a.residual = res; a.out = out;
+    a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Ho * a.Wo; a.ldrb = ldrb;
+    a.H = H; a.W = W; a.Cin = Cin; a.stride = stride; a.ups = ups;
+    note(u, 0, 2.0 * a.M * a.N * a.K);
+    RUN(ctx_gemm_dispatch(a, true, u->s));
+}
+static void op_gn(ctx_unet *u, const f16 *x, size_t g, size_t b, int B, int HW, int C, float eps, int silu, f16 *y, void *stats)
+{
+    note(u, 2, 0, 2);
+    RUN(ctx_groupnorm_f16(x, u->W + g, u->W + b, B, HW, C, u->cfg.groups, eps, silu, y, stats, u->s));
+}
+static void op_ln(ctx_unet *u, const f16 *x, size_t g, size_t b, int64_t rows, int C, f16 *y)
+{
+    note(u, 2, 0);
+    RUN(ctx_layernorm_f16(x, u->W + g, u->W + b, rows, C, 1e-5f, y, u->s));
+}
+static void op_attn(ctx_unet *u, const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, int Skv, int heads, int qs, int kvs, f16 *O)
+{
+    int Sp = cdiv(Skv, 64) * 64;
+    f16 *vt = u->allocH((size_t)B * heads * 64 * Sp);
+    note(u, 2, 0);
+    RUN(ctx_transpose_v_f16(V, B, Skv, kvs, heads, Sp, vt, u->s));
+    note(u, 1, 4.0 * B * heads * (double)Sq * Skv * 64);
+    RUN(ctx_attention_core(Q, K, vt, B, Sq, Skv, Sp, heads, qs, kvs, 0.125f, O, heads * 64, u->s));
+}
+
+struct FwdCtx {
+    int B, L;
+    const f16 *tproj;   // [B, temb_rows]
+    const f16 *ctx16;   // [B*L, cd]
+    void *gn_stats;
+};
+
+static f16 *run_resnet(ctx_unet *u, const FwdCtx &f, const ResP &r, const f16 *x, int H, int W, f16 *out)
+{
+    const int B = f.B, HW = H * W, M = B * HW;
+    size_t mark = u->top;
+    f16 *t1 = u->allocH((size_t)M * r.cin);
+    op_gn(u, x, r.n1g, r.n1b, B, HW, r.cin, u->cfg.norm_eps, 1, t1, f.gn_stats);
+    f16 *h = u->allocH((size_t)M * r.cout);
+    op_conv(u, t1, r.c1w, r.c1b, f.tproj ? f.tproj + r.temb_row : nullptr, u->temb_rows, nullptr, B, H, W, r.cin, r.cout, 1, 0, h);
+    f16 *t2 = u->allocH((size_t)M * r.cout);
+    op_gn(u, h, r.n2g, r.n2b, B, HW, r.cout, u->cfg.norm_eps, 1, t2, f.gn_stats);
+    const f16 *sc = x;
+    if (r.cin != r.cout) {
+        f16 *s2 = u->allocH((size_t)M * r.cout);
+        op_gemm(u, x, r.scw, r.scb, true, nullptr, M, r.cout, r.cin, s2);
+        sc = s2;
+    }
+    op_conv(u, t2, r.c2w, r.c2b, nullptr, 0, sc, B, H, W, r.cout, r.cout, 1, 0, out);
+    u->top = mark;
+    return out;
+}
+
+static f16 *run_transformer(ctx_unet *u, const FwdCtx &f, const TrP &t, const f16 *x, int H, int W, f16 *out)
+{
+    const int B = f.B, S = H * W, M = B * S, C = t.C, cd = u->cfg.cross_attention_dim;
+    size_t mark = u->top;
+    f16 *g = u->allocH((size_t)M * C);
+    op_gn(u, x, t.ng, t.nb, B, S, C, 1e-6f, 0, g, f.gn_stats);
+    f16 *h0 = u->allocH((size_t)M * C);
+    op_gemm(u, g, t.piw, t.pib, true, nullptr, M, C, C, h0);
+    // self attention
+    f16 *l = g;   // reuse
+    op_ln(u, h0, t.l1g, t.l1b, M, C, l);
+    f16 *qkv = u->allocH((size_t)M * 3 * C);
+    op_gemm(u, l, t.qkv, 0, false, nullptr, M, 3 * C, C, qkv);
+    f16 *a = u->allocH((size_t)M * C);
+    op_attn(u, qkv, qkv + C, qkv + 2 * C, B, S, S, t.heads, 3 * C, 3 * C, a);
+    f16 *h1 = u->allocH((size_t)M * C);
+    op_gemm(u, a, t.o1w, t.o1b, true, h0, M, C, C, h1);
+    // cross attention
+    op_ln(u, h1, t.l2g, t.l2b, M, C, l);
+    f16 *q = a;   // reuse
+    op_gemm(u, l, t.q2, 0, false, nullptr, M, C, C, q);
+    f16 *kv = u->allocH((size_t)B * f.L * 2 * C);
+    op_gemm(u, f.ctx16, t.kv2, 0, false, nullptr, B * f.L, 2 * C, cd, kv);
+    f16 *a2 = u->allocH((size_t)M * C);
+    op_attn(u, q, kv, kv + C, B, S, f.L, t.heads, C, 2 * C, a2);
+    f16 *h2 = h0;  // h0 is dead after h1 was produced
+    op_gemm(u, a2, t.o2w, t.o2b, true, h1, M, C, C, h2);
+    // feed forward (GEGLU fused into the first GEMM's epilogue)
+    op_ln(u, h2, t.l3g, t.l3b, M, C, l);
+    f16 *ff = u->allocH((size_t)M * 4 * C);
+    op_gemm(u, l, t.f1w, t.f1b, true, nullptr, M, 8 * C, C, ff, 1);
+    f16 *h3 = h1;
+    op_gemm(u, ff, t.f2w, t.f2b, true, h2, M, C, 4 * C, h3);
+    op_gemm(u, h3, t.pow_, t.pob, true, x, M, C, C, out);
+    u->top = mark;
+    return out;
+}
+
+static int unet_run(ctx_unet *u, const float *sample, const float *timestep, const float *ctx, int B, int H, int W, int L, float *out)
+{
+    const ctx_unet_config_t &c = u->cfg;
+    const int n = c.n_levels, lpb = c.layers_per_block;
+    const int *ch = c.block_out_channels;
+    u->top = 0; u->peak = 0; u->rc = 0;
+    for (int k = 0; k < 3; ++k) { u->launches[k] = 0; u->flops[k] = 0; }
+    FwdCtx f; f.B = B; f.L = L;
+    f.gn_stats = u->alloc((size_t)ctx_groupnorm_ws_bytes(B, c.groups));
+    // time embedding
+    f16 *te0 = u->allocH((size_t)B * ch[0]);
+    note(u, 2, 0); RUN(ctx_time_embed_f16(timestep, B, ch[0], te0, u->s));
+    f16 *te1 = u->allocH((size_t)B * u->temb_dim);
+    note(u, 2, 2.0 * B * ch[0] * u->temb_dim); RUN(ctx_gemv_f16(te0, u->W + u->t1w, u->W + u->t1b, B, u->temb_dim, ch[0], 0, 1, te1, u->s));
+    f16 *te2 = u->allocH((size_t)B * u->temb_dim);
+    note(u, 2, 2.0 * B * u->temb_dim * u->temb_dim); RUN(ctx_gemv_f16(te1, u->W + u->t2w, u->W + u->t2b, B, u->temb_dim, u->temb_dim, 0, 0, te2, u->s));
+    f16 *tproj = u->allocH((size_t)B * u->temb_rows);
+    note(u, 2, 2.0 * B * u->temb_rows * u->temb_dim); RUN(ctx_gemv_f16(te2, u->W + u->tpw, u->W + u->tpb, B, u->temb_rows, u->temb_dim, 1, 0, tproj, u->s));
+    f.tproj = tproj;
+    f16 *ctx16 = u->allocH((size_t)B * L * c.cross_attention_dim);
+    note(u, 2, 0); RUN(ctx_f32_to_f16(ctx, (int64_t)B * L * c.cross_attention_dim, ctx16, u->s));
+    f.ctx16 = ctx16;
+
+    int h = H, w = W;
+    f16 *x = u->allocH((size_t)B * h * w * ch[0]);
+    note(u, 2, 2.0 * B * h * w * ch[0] * c.in_channels * 9); RUN(ctx_conv_in_f16(sample, u->W + u->ciw, u->W + u->cib, B, c.in_channels, h, w, ch[0], x, u->s));
+
+    struct Skip { f16 *p; int C, h, w; };
+    std::vector<Skip> skips;
+    skips.push_back({x, ch[0], h, w});
+    int cur = ch[0];
+    for (int i = 0; i < n; ++i) {
+        LevelP &Lv = u->down[i];
+        for (int j = 0; j < lpb; ++j) {
+            int cout = Lv.res[j].cout;
+            f16 *o = u->allocH((size_t)B * h * w * cout);
+            if (Lv.has_attn) {
+                size_t mark = u->top;
+                f16 *t = u->allocH((size_t)B * h * w * cout);
+                run_resnet(u, f, Lv.res[j], x, h, w, t);
+                run_transformer(u, f, Lv.tr[j], t, h, w, o);
+                u->top = mark;
+            } else run_resnet(u, f, Lv.res[j], x, h, w, o);
+            x = o; cur = cout;
+            skips.push_back({x, cur, h, w});
+        }
+        if (Lv.has_sampler) {
+            int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+            f16 *o = u->allocH((size_t)B * ho * wo * cur);
+            op_conv(u, x, Lv.sw, Lv.sb, nullptr, 0, nullptr, B, h, w, cur, cur, 2, 0, o);
+            x = o; h = ho; w = wo;
+            skips.push_back({x, cur, h, w});
+        }
+    }
+    {
+        f16 *o1 = u->allocH((size_t)B * h * w * cur);
+        run_resnet(u, f, u->mid.res[0], x, h, w, o1);
+        f16 *o2 = u->allocH((size_t)B * h * w * cur);
+        run_transformer(u, f, u->mid.tr[0], o1, h, w, o2);
+        f16 *o3 = o1 == x ? u->allocH((size_t)B * h * w * cur) : u->allocH((size_t)B * h * w * cur);
+        run_resnet(u, f, u->mid.res[1], o2, h, w, o3);
+        x = o3;
+    }
+    for (int i = 0; i < n; ++i) {
+        LevelP &Lv = u->up[i];
+        for (int j = 0; j <= lpb; ++j) {
+            Skip sk = skips.back(); skips.pop_back();
+            if (sk.h != h || sk.w != w) { ctx_set_error("unet: skip size mismatch (H, W must be multiples of %d)", 1 << (n - 1)); return CTX_E_ARG; }
+            int cin = cur + sk.C, cout = Lv.res[j].cout;
+            f16 *o = u->allocH((size_t)B * h * w * cout);
+            size_t mark = u->top;
+            f16 *cat = u->allocH((size_t)B * h * w * cin);
+            note(u, 2, 0); RUN(ctx_concat_f16(x, sk.p, (int64_t)B * h * w, cur, sk.C, cat, u->s));
+            if (Lv.has_attn) {
+                f16 *t = u->allocH((size_t)B * h * w * cout);
+                run_resnet(u, f, Lv.res[j], cat, h, w, t);
+                run_transformer(u, f, Lv.tr[j], t, h, w, o);
+            } else run_resnet(u, f, Lv.res[j], cat, h, w, o);
+            u->top = mark;
+            x = o; cur = cout;
+        }
+        if (Lv.has_sampler) {
+            f16 *o = u->allocH((size_t)B * (2 * h) * (2 * w) * cur);
+            op_conv(u, x, Lv.sw, Lv.sb, nullptr, 0, nullptr, B, h, w, cur, cur, 1, 1, o);
+            x = o; h *= 2; w *= 2;
+        }
+    }
+    f16 *y = u->allocH((size_t)B * h * w * cur);
+    op_gn(u, x, u->cng, u->cnb, B, h * w, cur, c.norm_eps, 1, y, f.gn_stats);
+    note(u, 2, 2.0 * B * h * w * cur * c.out_channels * 9);
+    RUN(ctx_conv_out_f16(y, u->W + u->cow, u->W + u->cob, B, h, w, cur, c.out_channels, out, u->s));
+    if (!u->dry && u->rc == 0) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ctx_set_error("unet_forward: launch failed: %s", hipGetErrorString(e)); return CTX_E_LAUNCH; }
+    }
+    return u->rc;
+}
+
+static int check_dims(const ctx_unet *u, int B, int H, int W, int L)
+{
+    int div = 1 << (u->cfg.n_levels - 1);
+    if (B < 1 || B > 4 || H < div || W < div || H % div || W % div || L < 1) {
+        ctx_set_error("unet: need 1<=B<=4, H,W multiples of %d, ctx_len>=1 (B=%d H=%d W=%d L=%d)", div, B, H, W, L);
+        return CTX_E_ARG;
+    }
+    return 0;
+}
+
+extern "C" int64_t ctx_unet_workspace_bytes(const ctx_unet_t *cu, int32_t B, int32_t H, int32_t W, int32_t ctx_len)
+{
+    ctx_unet *u = const_cast<ctx_unet *>(cu);
+    if (!u || check_dims(u, B, H, W, ctx_len)) return -1;
+    bool was = u->dry;
+    u->dry = true;
+    unet_run(u, nullptr, nullptr, nullptr, B, H, W, ctx_len, nullptr);
+    u->dry = was;
+    return (int64_t)u->peak + 4096;
+}
+
+extern "C" int32_t ctx_unet_forward(ctx_unet_t *u, const float *sample, const float *timestep, const float *ctx, int32_t B,
+                                    int32_t H, int32_t W, int32_t ctx_len, float *out, ctx_stream_t stream)
+{
+    CTX_REQUIRE(u && sample && timestep && ctx && out, "unet_forward: null pointer");
+    CTX_REQUIRE(u->W && u->ws, "unet_forward: ctx_unet_bind() first");
+    if (check_dims(u, B, H, W, ctx_len)) return CTX_E_ARG;
+    u->s = (hipStream_t)stream;
+    u->dry = false;
+    return unet_run(u, sample, timestep, ctx, B, H, W, ctx_len, out);
+}
+
+extern "C" int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops)
+{
+    CTX_REQUIRE(u && klass >= 0 && klass < 3 && launches && flops, "unet_stats: bad args");
+    *launches = u->launches[klass];
+    *flops = u->flops[klass];
+    return CTX_OK;
+}

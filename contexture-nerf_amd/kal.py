@@ -141,7 +141,12 @@ class _TextureMapping(torch.autograd.Function):
             g = torch.zeros(Cc, T, T, device=go.device)
             L.check(lib.ctx_texture_mapping_bwd(L.ptr(go), L.ptr(uvc), B, HW, Cc, T, L.ptr(mask_idx if has_mask else None),
                                                 L.ptr(g), L.stream()))
-            g = g[None].expand(tshape) if Bt > 1 else g[None]
+            if Bt > 1:      # input was an expand(): autograd sums the batch slices, so put the whole sum in slice 0
+                full = torch.zeros(tshape, device=go.device)
+                full[0] = g
+                g = full
+            else:
+                g = g[None]
         else:
             g = torch.zeros(Bt, Cc, T, T, device=go.device)
             for b in range(Bt):

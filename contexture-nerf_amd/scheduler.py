@@ -1,0 +1,123 @@
+"""PNDMScheduler: the diffusers seam used at src/stable_diffusion_depth.py:98-100,298,310,364,514
+(`set_timesteps`, `.timesteps`, `.step(eps, t, x)['prev_sample']`, `.add_noise`, `.scale_model_input`,
+`.alphas_cumprod`), PLMS-only (`skip_prk_steps=True`), epsilon prediction.
+
+`step()` keeps the diffusers call shape.  `step_cfg()` additionally fuses the classifier-free-guidance
+combine (stable_diffusion_depth.py:428-430) with the multistep update in one HIP kernel that reads the
+[2,...] noise prediction once; the epsilon history lives in a 4-slot device ring.
+"""
+import ctypes as C
+import numpy as np
+import torch
+from . import _lib as L
+
+
+class PNDMScheduler:
+    def __init__(self, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
+                 steps_offset=1, skip_prk_steps=True, **kw):
+        if beta_schedule != "scaled_linear" or not skip_prk_steps:
+            raise L.CtxError("PNDMScheduler: only the reference's configuration (scaled_linear, skip_prk_steps) is implemented")
+        self.num_train_timesteps = num_train_timesteps
+        self.steps_offset = steps_offset
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self._ac = self.alphas_cumprod.numpy()
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+        self.num_inference_steps = None
+        self._ring = None
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round() + self.steps_offset
+        plms = np.concatenate([ts[:-1], ts[-2:-1], ts[-1:]])[::-1].copy()
+        self.timesteps = torch.from_numpy(plms.astype(np.int64))
+        if device is not None:
+            self.timesteps = self.timesteps.to(device)
+        self.counter = 0
+        self._n_ets = 0
+        self._head = -1
+        self._ring = None
+        self._cur = None
+
+    def scale_model_input(self, sample, *a, **k):
+        return sample
+
+    def add_noise(self, original_samples, noise, timesteps):
+        t = timesteps.reshape(-1).long().cpu()
+        a = self.alphas_cumprod[t].to(original_samples.device, original_samples.dtype)
+        sa, sb = (a ** 0.5).flatten(), ((1 - a) ** 0.5).flatten()
+        while sa.dim() < original_samples.dim():
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * original_samples + sb * noise
+
+    # -- coefficient bookkeeping shared by step() and step_cfg() ------------------------------------------------
+    def _coeffs(self, t, prev_t):
+        a = self._ac[t]
+        ap = self._ac[prev_t] if prev_t >= 0 else self._ac[0]
+        b, bp = np.float32(1) - a, np.float32(1) - ap
+        sample_coeff = np.float32((ap / a) ** 0.5)
+        den = a * np.float32(bp ** 0.5) + np.float32((a * b * ap) ** 0.5)
+        return float(sample_coeff), float((ap - a) / den)
+
+    def _advance(self, timestep):
+        """-> (mode, head, coef4, t_eff, prev_t) and updates counters exactly like diffusers step_plms."""
+        t = int(timestep)
+        ratio = self.num_train_timesteps // self.num_inference_steps
+        prev_t = t - ratio
+        if self.counter != 1:
+            self._n_ets = min(self._n_ets + 1, 4)
+            self._head = (self._head + 1) & 3
+            mode = 2 if self.counter == 0 else 0
+        else:
+            prev_t, t = t, t + ratio
+            mode = 1
+        n = self._n_ets
+        if mode == 1 or n == 1:
+            coef = [1.0, 0.0, 0.0, 0.0]
+        elif n == 2:
+            coef = [1.5, -0.5, 0.0, 0.0]
+        elif n == 3:
+            coef = [23 / 12, -16 / 12, 5 / 12, 0.0]
+        else:
+            coef = [55 / 24, -59 / 24, 37 / 24, -9 / 24]
+        self.counter += 1
+        return mode, self._head, coef, t, prev_t
+
+    def _buffers(self, sample):
+        n = sample.numel()
+        if self._ring is None or self._ring.shape[1] != n or self._ring.device != sample.device:
+            self._ring = torch.zeros(4, n, device=sample.device)
+            self._cur = torch.empty(n, device=sample.device)
+
+    def step_cfg(self, noise_pred_pair, guidance_scale, timestep, sample):
+        """noise_pred_pair [2,...] = (uncond, text) -> {'prev_sample'}; fused CFG + PLMS (HIP)."""
+        lib = L.load()
+        x = L.f32c(sample).clone()
+        pair = L.f32c(noise_pred_pair)
+        if pair.numel() != 2 * x.numel():
+            raise L.CtxError("step_cfg: noise_pred_pair must stack (uncond, text) along dim 0")
+        self._buffers(x)
+        mode, head, coef, t, prev_t = self._advance(timestep)
+        sc, ec = self._coeffs(t, prev_t)
+        c4 = (C.c_float * 4)(*coef)
+        L.check(lib.ctx_cfg_plms_step(L.ptr(pair, torch.float32, "noise_pred"), x.numel(), float(guidance_scale), L.ptr(self._ring),
+                                      head, c4, sc, ec, mode, L.ptr(self._cur), L.ptr(x), L.stream()))
+        return {'prev_sample': x}
+
+    def step(self, model_output, timestep, sample, **kw):
+        """diffusers call shape (already-guided epsilon)."""
+        pair = torch.stack([model_output, model_output])
+        return self.step_cfg(pair, 0.0, timestep, sample)
+
+
+class DDPMScheduler:
+    """add_noise-only subset used on the reference's SDS path (src/training/trainer.py:746)."""
+    def __init__(self, beta_start=0.00085, beta_end=0.012, num_train_timesteps=1000, **kw):
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+
+    add_noise = PNDMScheduler.add_noise

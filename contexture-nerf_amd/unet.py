@@ -1,0 +1,183 @@
+"""UNet2DConditionModel: the seam `self.unet(x, t, encoder_hidden_states=ctx)['sample']` of
+src/stable_diffusion_depth.py:422-423 (diffusers 0.27.2 class), executed by the HIP engine in
+libctxnerf.so (fp16 MFMA conv / GEMM / attention, fp32 accumulation).
+
+Parameters use diffusers' state_dict names, so `load_state_dict` accepts a diffusers checkpoint
+(safetensors of stabilityai/stable-diffusion-2-depth/unet) unchanged; with no checkpoint (offline) the
+weights are seeded random-init with torch's default Conv2d/Linear initialisers, as BASELINE.json prescribes.
+"""
+import ctypes as C
+import math
+import torch
+from . import _lib as L
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("n_levels", C.c_int32),
+                ("block_out_channels", C.c_int32 * 4), ("heads", C.c_int32 * 4),
+                ("down_attn", C.c_int32 * 4), ("up_attn", C.c_int32 * 4), ("layers_per_block", C.c_int32),
+                ("cross_attention_dim", C.c_int32), ("groups", C.c_int32), ("norm_eps", C.c_float)]
+
+
+SD2_DEPTH = dict(in_channels=5, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                 down_attn=(True, True, True, False), up_attn=(False, True, True, True),
+                 cross_attention_dim=1024, heads=(5, 10, 20, 20), groups=32, norm_eps=1e-5)
+
+
+def _pad4(xs):
+    xs = [int(x) for x in xs]
+    return (C.c_int32 * 4)(*(xs + [0] * (4 - len(xs))))
+
+
+class UNet2DConditionModel:
+    def __init__(self, config=None, device="cuda:0", seed=0, init=True):
+        cfg = dict(SD2_DEPTH if config is None else config)
+        self.config = cfg
+        self.in_channels = cfg['in_channels']
+        self.device = torch.device(device)
+        self._lib = L.load()
+        c = UNetConfig(cfg['in_channels'], cfg['out_channels'], len(cfg['block_out_channels']),
+                       _pad4(cfg['block_out_channels']), _pad4(cfg['heads']), _pad4(cfg['down_attn']),
+                       _pad4(cfg['up_attn']), cfg['layers_per_block'], cfg['cross_attention_dim'], cfg['groups'],
+                       cfg['norm_eps'])
+        self._h = self._lib.ctx_unet_create(C.byref(c))
+        if not self._h:
+            raise L.CtxError("ctx_unet_create: " + self._lib.ctx_last_error().decode())
+        self._names, self._shapes = [], []
+        shp = (C.c_int64 * 4)()
+        for i in range(self._lib.ctx_unet_param_count(self._h)):
+            nd = self._lib.ctx_unet_param_shape(self._h, i, shp)
+            self._names.append(self._lib.ctx_unet_param_name(self._h, i).decode())
+            self._shapes.append(tuple(int(shp[k]) for k in range(nd)))
+        self._index = {n: i for i, n in enumerate(self._names)}
+        self._weights = None
+        self._ws = None
+        self._ws_key = None
+        self._t = None
+        if self.device.type == 'cuda':
+            self._weights = torch.empty(self._lib.ctx_unet_weight_bytes(self._h), dtype=torch.uint8, device=self.device)
+            self._ws = torch.empty(256, dtype=torch.uint8, device=self.device)
+            self._bind()
+            if init:
+                self.init_random(seed)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self._lib.ctx_unet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- parameter table ---------------------------------------------------------------------------------
+    def param_shapes(self):
+        return dict(zip(self._names, self._shapes))
+
+    def num_parameters(self):
+        return sum(math.prod(s) for s in self._shapes)
+
+    def _bind(self):
+        L.check(self._lib.ctx_unet_bind(self._h, L.ptr(self._weights), L.ptr(self._ws), self._ws.numel()))
+
+    def _set(self, i, t):
+        t = L.f32c(t, self.device)
+        if tuple(t.shape) != self._shapes[i]:
+            raise L.CtxError(f"{self._names[i]}: shape {tuple(t.shape)} != {self._shapes[i]}")
+        L.check(self._lib.ctx_unet_set_param(self._h, i, L.ptr(t, torch.float32, self._names[i]), L.stream()))
+        return t
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [n for n in self._names if n not in sd]
+        extra = [k for k in sd if k not in self._index]
+        if strict and (missing or extra):
+            raise L.CtxError(f"load_state_dict: missing {missing[:5]}... ({len(missing)}), unexpected {extra[:5]}... ({len(extra)})")
+        keep = []
+        for n, i in self._index.items():
+            if n in sd:
+                keep.append(self._set(i, sd[n]))
+        torch.cuda.synchronize(self.device)   # sources must outlive the async repack kernels
+        return missing, extra
+
+    def init_random(self, seed=0):
+        """torch default initialisers (kaiming_uniform(a=sqrt 5) => U(-1/sqrt(fan_in), +)), norms = (1, 0)."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        fan = {}
+        for n, s in zip(self._names, self._shapes):
+            if n.endswith('.weight') and len(s) >= 2:
+                fan[n[:-7]] = math.prod(s[1:])
+        for i, (n, s) in enumerate(zip(self._names, self._shapes)):
+            base = n.rsplit('.', 1)[0]
+            if len(s) == 1 and base not in fan:                 # norm affine
+                t = torch.ones(s, device=self.device) if n.endswith('.weight') else torch.zeros(s, device=self.device)
+            else:
+                b = 1.0 / math.sqrt(fan[base])
+                t = (torch.rand(s, generator=g, device=self.device) * 2 - 1) * b
+            self._set(i, t)
+            if i % 64 == 63:
+                torch.cuda.synchronize(self.device)
+        torch.cuda.synchronize(self.device)
+
+    # -- forward ---------------------------------------------------------------------------------------------
+    def workspace_bytes(self, B, H, W, ctx_len):
+        n = self._lib.ctx_unet_workspace_bytes(self._h, B, H, W, ctx_len)
+        if n < 0:
+            raise L.CtxError(self._lib.ctx_last_error().decode())
+        return n
+
+    def flops(self, B, H, W, ctx_len):
+        """Algorithmic FLOPs of one forward by kernel class: {'gemm_conv', 'attention', 'other'} + launches."""
+        self.workspace_bytes(B, H, W, ctx_len)            # dry run fills the counters
+        out = {}
+        for k, name in enumerate(('gemm_conv', 'attention', 'other')):
+            n, f = C.c_int64(), C.c_double()
+            L.check(self._lib.ctx_unet_stats(self._h, k, C.byref(n), C.byref(f)))
+            out[name] = (n.value, f.value)
+        return out
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, **kw):
+        return self.forward(sample, timestep, encoder_hidden_states)
+
+    def forward(self, sample, timestep, encoder_hidden_states):
+        x = L.f32c(sample, self.device)
+        ctx = L.f32c(encoder_hidden_states, self.device)
+        B, Cin, H, W = x.shape
+        if Cin != self.in_channels:
+            raise L.CtxError(f"unet: expected {self.in_channels} input channels, got {Cin}")
+        if ctx.shape[0] != B or ctx.shape[2] != self.config['cross_attention_dim']:
+            raise L.CtxError(f"unet: encoder_hidden_states shape {tuple(ctx.shape)} does not match batch {B} / dim "
+                             f"{self.config['cross_attention_dim']}")
+        Lc = ctx.shape[1]
+        key = (B, H, W, Lc)
+        if self._ws_key != key:
+            need = self.workspace_bytes(B, H, W, Lc)
+            if self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self._bind()
+            self._ws_key = key
+        if isinstance(timestep, torch.Tensor) and timestep.is_cuda and timestep.dtype == torch.float32 and timestep.numel() == 1:
+            t = timestep.reshape(1)
+        else:
+            if self._t is None:
+                self._t = torch.empty(1, dtype=torch.float32, device=self.device)
+            self._t.fill_(float(timestep))
+            t = self._t
+        out = torch.empty(B, self.config['out_channels'], H, W, device=self.device)
+        L.check(self._lib.ctx_unet_forward(self._h, L.ptr(x, torch.float32, "sample"), L.ptr(t), L.ptr(ctx), B, H, W, Lc,
+                                           L.ptr(out), L.stream()))
+        return {'sample': out}
+
+
+def smoke_check(dev):
+    """One tiny denoise evaluation against the fp32 oracle (called from __graft_entry__.smoke)."""
+    from oracle import unet_ref
+    cfg = unet_ref.tiny_config()
+    torch.manual_seed(0)
+    ref = unet_ref.randomize_affine(unet_ref.UNet2DConditionModelRef(cfg)).eval()
+    net = UNet2DConditionModel(cfg, device=dev, init=False)
+    net.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 5, 16, 16); ctx = torch.randn(2, 7, cfg['cross_attention_dim'])
+    with torch.no_grad():
+        want = ref(x, torch.tensor(481.0), ctx)['sample']
+    got = net(x.to(dev), 481.0, ctx.to(dev))['sample'].cpu()
+    rel = (got - want).norm() / want.norm()
+    assert rel < 5e-3, f"UNet smoke: relative error {rel:.3e}"

@@ -158,7 +158,7 @@ int32_t ctx_unet_forward(ctx_unet_t *u, const float *sample, const float *timest
 int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops);
 
 /* Building blocks, exported for unit parity tests (fp16 tensors passed as uint16 bit patterns). */
-/* C[M,N] = A[M,K] @ Wt[N,K]^T (+bias[N]) (+residual[M,N]); K%32==0, N%8==0. */
+/* C[M,N] = A[M,K] @ Wt[N,K]^T (+bias[N]) (+residual[M,N]); K%64==0, N%8==0. */
 int32_t ctx_gemm_f16(const void *A, const void *Wt, const void *bias, const void *residual,
                      int32_t M, int32_t N, int32_t K, void *C, ctx_stream_t stream);
 /* x[B,H,W,Cin] (NHWC f16) * w[Cout,3,3,Cin] stride s pad 1 (+bias) (+rowbias[B,Cout]) (+res) -> [B,Ho,Wo,Cout];
@@ -166,22 +166,25 @@ int32_t ctx_gemm_f16(const void *A, const void *Wt, const void *bias, const void
 int32_t ctx_conv3x3_f16(const void *x, const void *w, const void *bias, const void *rowbias,
                         const void *residual, int32_t B, int32_t H, int32_t W, int32_t Cin,
                         int32_t Cout, int32_t stride, int32_t upsample, void *y, ctx_stream_t stream);
-/* GroupNorm(+SiLU) over NHWC f16; stats_ws: B*groups*2 floats. */
+/* GroupNorm(+SiLU) over NHWC f16; stats_ws: ctx_groupnorm_ws_bytes(B, groups). */
+int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups);
 int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const void *beta, int32_t B, int32_t HW,
                           int32_t C, int32_t groups, float eps, int32_t silu, void *y, void *stats_ws,
                           ctx_stream_t stream);
 int32_t ctx_layernorm_f16(const void *x, const void *gamma, const void *beta, int64_t rows, int32_t C,
                           float eps, void *y, ctx_stream_t stream);
-/* softmax(Q K^T * scale) V; Q[B,Sq,heads*64], K[B,Skv,heads*64], V likewise (f16) -> O[B,Sq,heads*64]. */
+/* softmax(Q K^T * scale) V; Q[B,Sq,heads*64], K[B,Skv,heads*64], V likewise (f16) -> O[B,Sq,heads*64];
+   row strides in elements.  vt_ws: ctx_attention_ws_bytes() scratch for the transposed V. */
+int64_t ctx_attention_ws_bytes(int32_t B, int32_t Skv, int32_t heads);
 int32_t ctx_attention_f16(const void *Q, const void *K, const void *V, int32_t B, int32_t Sq, int32_t Skv,
                           int32_t heads, int32_t q_stride, int32_t kv_stride, float scale, void *O,
-                          int32_t o_stride, ctx_stream_t stream);
+                          int32_t o_stride, void *vt_ws, ctx_stream_t stream);
 /* GEGLU: y[M,C4] = h[:, :C4] * gelu(h[:, C4:])  for h[M,2*C4] f16. */
 int32_t ctx_geglu_f16(const void *h, int64_t M, int32_t C4, void *y, ctx_stream_t stream);
 
 /* CFG combine + PNDM/PLMS update fused (stable_diffusion_depth.py:428-430,514; diffusers PNDMScheduler
    step_plms with skip_prk_steps).  eps_pair[2,n] (uncond, text); ets[4,n] history ring (newest at
-   slot `head`); coef[4] linear-multistep weights for (e_t, e_t-1, e_t-2, e_t-3) after insertion;
+   slot `head`); coef4 = HOST float[4] linear-multistep weights for (e_t, e_t-1, e_t-2, e_t-3) after insertion;
    sample_coeff, eps_coeff from _get_prev_sample; x[n] updated in place; also writes the blended
    epsilon into ets[head]. mode 0: normal; 1: second call of the first step (average with ets[head],
    use cur_sample_ws as x). */

@@ -39,7 +39,8 @@ def texture_from_mlp(mlp_out, res):
 
 def uv_grid(res):
     """textured_mesh.py:269-273: meshgrid(linspace, linspace, indexing='xy') -> row i <-> v, col j <-> u."""
-    l = np.linspace(0, 1, res, dtype=np.float32)
+    import torch  # torch.linspace's float32 rounding (symmetric fill) is what the reference feeds the embedder
+    l = torch.linspace(0, 1, res).numpy()
     u, v = np.meshgrid(l, l, indexing='xy')
     return np.stack([u, v], -1).reshape(-1, 2)
 

@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ctx_nerf.h declares (no compute calls),
+the ctypes table mirrors the header, and the host-only parts of the ABI (UNet parameter table, size queries)
+agree with the oracle's module graph."""
+import ctypes as C
+import os
+import re
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "ctx_nerf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from contexture_nerf_amd import _lib as L
+    assert os.environ.get("CTX_ALLOW_PARTIAL") != "1"
+    lib = L.load()
+    names = _header_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ctx_nerf.h but not exported"
+        assert n in L.SIGNATURES, f"{n} has no ctypes signature"
+    for n in L.SIGNATURES:
+        assert n in names, f"{n} bound in _lib.py but not declared in the header"
+    assert lib.ctx_version() >= 100
+
+
+def test_product_fails_loudly_without_device_tensors():
+    from contexture_nerf_amd import _lib as L, kal
+    with pytest.raises(L.CtxError, match="device tensor"):
+        kal.render.mesh.rasterize(8, 8, torch.zeros(1, 1, 3), torch.zeros(1, 1, 3, 2), torch.zeros(1, 1, 3, 1))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "contexture-nerf_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            body = src.split("def smoke_check")[0]        # smoke_check is the one sanctioned oracle user
+            assert "oracle" not in re.sub(r'""".*?"""', "", body, flags=re.S), f"{fn} references the oracle"
+
+
+def test_unet_param_table_matches_diffusers_naming():
+    from contexture_nerf_amd.unet import UNet2DConditionModel, SD2_DEPTH
+    from oracle import unet_ref
+    for cfg in (unet_ref.tiny_config(), unet_ref.tiny_config(ch=(64, 128, 256, 256), heads=(1, 2, 4, 4), ctx_dim=128)):
+        net = UNet2DConditionModel(cfg, device="cpu", init=False)
+        ref = unet_ref.UNet2DConditionModelRef(cfg)
+        assert net.param_shapes() == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    net = UNet2DConditionModel(SD2_DEPTH, device="cpu", init=False)
+    assert net.in_channels == 5
+    assert 865e6 < net.num_parameters() < 867e6
+    shapes = net.param_shapes()
+    assert shapes["conv_in.weight"] == (320, 5, 3, 3)
+    assert shapes["up_blocks.1.resnets.2.conv1.weight"] == (1280, 1920, 3, 3)
+    assert shapes["down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (320, 1024)
+    assert shapes["mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight"] == (10240, 1280)
+    # FLOP accounting of the engine == the oracle's count == SURVEY §8d
+    for hw, want in ((32, 181.1e9), (64, 804.3e9), (96, 2149.2e9)):
+        fl = net.flops(2, hw, hw, 77)
+        total = sum(v[1] for v in fl.values()) / 2
+        assert abs(total - want) / want < 2e-3, (hw, total)
+        assert abs(total - unet_ref.count_flops(unet_ref.SD2_DEPTH, hw, hw)['total']) / want < 1e-6
+
+
+def test_size_queries():
+    from contexture_nerf_amd import _lib as L
+    lib = L.load()
+    assert lib.ctx_rasterize_ws_bytes(1200, 1200, 7, 7500) > 7 * 361 * 7500 * 4
+    assert lib.ctx_uvmlp_packed_bytes(8, 256, 42, 3, 4) > 483075 * 4
+    assert lib.ctx_uvmlp_packed_bytes(8, 100, 42, 3, 4) == -1
+    assert lib.ctx_attention_ws_bytes(2, 77, 5) == 2 * 5 * 64 * 128 * 2
