@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — UNet denoise steps/sec on MI355X for the reference's per-view paint loop.
+
+A "step" is one iteration of the denoise loop of StableDiffusion.img2img_step
+(src/stable_diffusion_depth.py:331-514): CFG-batched UNet evaluation (batch 2: [uncond, text]) on
+[latents ; depth] followed by the CFG combine + PNDM/PLMS update.  N=1 workload = BASELINE.json configs[1]:
+one view @768^2 (latent 96^2), 50 scheduler steps, SD2-depth architecture, fp16 MFMA kernels, seeded
+random-init weights and synthetic text/depth inputs (no network for checkpoints or datasets).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+N>1: one process per GPU; the 6-8 views of a mesh shard one per rank (weak scaling: every rank denoises its
+own view, no data-path collective inside the denoise loop); value = total steps of all ranks / max time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--latent", type=int, default=96, help="latent side (96 = 768^2 image; 64 = 512^2)")
+    p.add_argument("--guidance", type=float, default=10.0)
+    p.add_argument("--cpu-baseline", type=int, default=1)
+    p.add_argument("--cpu-latent", type=int, default=0, help="latent side of the CPU sample (0 = auto)")
+    return p.parse_args()
+
+
+def cpu_baseline(latent, budget_s=45.0, forced=0):
+    """The oracle's fp32 PyTorch UNet (the reference's CPU behaviour: autocast is a no-op on CPU,
+    stable_diffusion_depth.py:330) timed on this box's host cores on ONE CFG-batched step."""
+    from oracle import unet_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    net = unet_ref.UNet2DConditionModelRef(unet_ref.SD2_DEPTH).eval()
+    build_s = time.perf_counter() - t0
+    ctx = torch.randn(2, 77, 1024)
+
+    def run(side):
+        x = torch.randn(2, 5, side, side)
+        with torch.no_grad():
+            t = time.perf_counter()
+            net(x, torch.tensor(501.0), ctx)
+            return time.perf_counter() - t
+    probe = run(32)                                           # 0.36 TFLOP: also warms the thread pool
+    fl = {s: 2 * unet_ref.count_flops(unet_ref.SD2_DEPTH, s, s)['total'] for s in (32, 64, 96)}
+    side = forced or latent
+    if not forced:
+        while side > 32 and probe * fl.get(side, fl[96]) / fl[32] > budget_s:
+            side = {96: 64, 64: 32}.get(side, 32)
+    dt = run(side) if side != 32 else min(probe, run(32))
+    scale = fl[side] / fl.get(latent, fl[96])                 # FLOP-ratio extrapolation when the sample is smaller
+    step_s = dt / scale
+    return {"value": round(1.0 / step_s, 5), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 CFG-batched UNet step (batch 2) at latent {side}^2, fp32 torch CPU oracle, {cores} threads, "
+                      f"{dt:.2f} s measured" + ("" if side == latent else f"; scaled to latent {latent}^2 by FLOP ratio {1 / scale:.2f}x")
+                      + f" (model build {build_s:.1f} s not counted)"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from contexture_nerf_amd import _lib as L
+    from contexture_nerf_amd.unet import UNet2DConditionModel
+    from contexture_nerf_amd.scheduler import PNDMScheduler
+    lib = L.load()
+    L.check(lib.ctx_device_check())
+
+    S = a.latent
+    unet = UNet2DConditionModel(device=dev, seed=0)           # SD2-depth architecture, 866 M params, random init
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)  # each rank = its own view
+    text_z = torch.randn(2, 77, 1024, generator=g, device=dev)
+    depth = torch.rand(1, 1, S, S, generator=g, device=dev) * 2 - 1
+    depth2 = torch.cat([depth] * 2)
+    sched = PNDMScheduler()
+    state = {"i": 0, "lat": None}
+
+    def new_view():
+        sched.set_timesteps(50)
+        state["i"] = 0
+        state["lat"] = torch.randn(1, 4, S, S, generator=g, device=dev)
+
+    def step():
+        if state["lat"] is None or state["i"] >= len(sched.timesteps):
+            new_view()
+        t = int(sched.timesteps[state["i"]])
+        lat = state["lat"]
+        x = torch.cat([torch.cat([lat] * 2), depth2], dim=1)                      # [2,5,S,S]
+        eps = unet(x, float(t), encoder_hidden_states=text_z)['sample']          # K14
+        state["lat"] = sched.step_cfg(eps, a.guidance, t, lat)['prev_sample']   # K15+K16 fused
+        state["i"] += 1
+
+    for _ in range(a.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(state["lat"]).all(), "non-finite latents"
+
+    # ---- live per-kernel timing (outside the timed region): dominant kernel = fp16 MFMA GEMM / implicit conv ------
+    fl = unet.flops(2, S, S, 77)
+    L.check(lib.ctx_profile_begin())
+    step()
+    torch.cuda.synchronize()
+    prof = {}
+    for k, name in ((0, "gemm_conv"), (1, "attention")):
+        ms, n = C.c_double(), C.c_int64()
+        L.check(lib.ctx_profile_end(k, C.byref(ms), C.byref(n)))
+        prof[name] = (ms.value, n.value)
+    gemm_ms, gemm_n = prof["gemm_conv"]
+    att_ms, att_n = prof["attention"]
+    gemm_fl = fl["gemm_conv"][1]
+    achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    total_fl = sum(v[1] for v in fl.values())
+
+    # multi-GPU exchange step of the path (once per mesh, not per denoise step): atlas all-reduce, timed separately
+    atlas_ms = None
+    if dist is not None:
+        atlas = torch.zeros(4, 1024, 1024, device=dev)
+        dist.all_reduce(atlas); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dist.all_reduce(atlas); torch.cuda.synchronize()
+        atlas_ms = (time.perf_counter() - t1) * 1e3
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        out = {
+            "metric": "UNet denoise steps/sec (CFG-batched SD2-depth UNet eval + PLMS update)",
+            "value": round(world * a.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: 1 view @{S * 8}^2 (latent {S}^2), 50 PLMS steps (51 UNet evals), "
+                                   "SD2-depth UNet fp16, CFG batch 2, guidance 10, random-init weights; "
+                                   "mesh substitution napoleon.obj -> n/a for this stage (denoise loop only)",
+                       "latent": S, "cfg_batch": 2, "ctx_len": 77, "views_per_rank": 1, "parallelism": f"view-shard x{world}"},
+            "tflops_per_step": round(total_fl / 1e12, 4),
+            "step_tflops_per_s": round(total_fl / 1e12 / (elapsed / a.steps), 2),
+            "sec_per_view_51_evals": round(51 * ms_per_step / 1e3, 3),
+            "sec_per_mesh_6_views_est": round(6 * 51 * ms_per_step / 1e3 / world if world <= 6 else 51 * ms_per_step / 1e3, 3),
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_f16 (GEMM + implicit-GEMM conv3x3, v_mfma_f32_32x32x16_f16)",
+                         "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
+                         "traffic": None, "launches_per_step": gemm_n, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_n, 1), 2),
+                         "flops_per_launch_avg": round(gemm_fl / max(gemm_n, 1) / 1e9, 3), "kernel_ms_per_step": round(gemm_ms, 3)},
+            "attention": {"kernel": "k_attention", "achieved": round(fl["attention"][1] / (att_ms * 1e-3) / 1e12, 2) if att_ms > 0 else 0.0,
+                          "unit": "TFLOP/s", "launches_per_step": att_n, "kernel_ms_per_step": round(att_ms, 3)},
+        }
+        if atlas_ms is not None:
+            out["atlas_allreduce_ms"] = round(atlas_ms, 3)
+        if world == 1 and a.cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(S, forced=a.cpu_latent)
+            except Exception as e:                      # never lose the GPU line to a host-side failure
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,8 @@ SIGNATURES = {
     "ctx_attention_f16": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i32, _vp, _vp]),
     "ctx_groupnorm_ws_bytes": (_i64, [_i32, _i32]),
     "ctx_geglu_f16": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "ctx_profile_begin": (_i32, []),
+    "ctx_profile_end": (_i32, [_i32, _vp, _vp]),
     "ctx_probe_mfma": (_i32, [_i32, _vp, _vp, _vp, _vp]),
     "ctx_cfg_plms_step": (_i32, [_vp, _i64, _f32, _vp, _i32, _vp, _f32, _f32, _i32, _vp, _vp, _vp]),
 }

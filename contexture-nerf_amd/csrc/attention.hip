@@ -10,6 +10,7 @@
 // ([B, heads, 64, Skv_pad], keys contiguous) so its fragment is two 8-byte LDS reads.
 #include "common.h"
 #include "kernels.h"
+#include <hip/hip_ext.h>
 #include <math.h>
 
 #define AT_KB 64                // keys per tile
@@ -161,7 +162,12 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq,
     a.Q = Q; a.K = K; a.Vt = Vt; a.O = O; a.Sq = Sq; a.Skv = Skv; a.Sp = Sp; a.heads = heads;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(k_attention, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, a);
+    if (ctx_prof_on()) {
+        hipEvent_t e0, e1;
+        ctx_prof_events(1, &e0, &e1);
+        hipExtLaunchKernelGGL(k_attention, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, e0, e1, 0, a);
+    } else
+        hipLaunchKernelGGL(k_attention, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ctx_set_error("attention launch failed: %s", hipGetErrorString(e));

@@ -16,6 +16,7 @@
 // zero padding by predication, optional fused nearest x2 upsample and stride 2).
 #include "common.h"
 #include "kernels.h"
+#include <hip/hip_ext.h>
 
 #define GK 64          // K-tile
 #define LDS_ROW 72     // f16 per LDS row (64 + 8 pad) = 144 B
@@ -206,7 +207,12 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
         (void)hipFuncSetAttribute((const void *)k_gemm_f16<WM, WN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_f16<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, a);
+    if (ctx_prof_on()) {
+        hipEvent_t e0, e1;
+        ctx_prof_events(0, &e0, &e1);
+        hipExtLaunchKernelGGL((k_gemm_f16<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, e0, e1, 0, a);
+    } else
+        hipLaunchKernelGGL((k_gemm_f16<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, a);
 }
 
 // Tile choice: 128x128 when N is a multiple of 128 (no masked columns), else 256x64.

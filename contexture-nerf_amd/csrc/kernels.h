@@ -30,3 +30,7 @@ int ctx_conv_out_f16(const f16 *x, const f16 *w, const f16 *bias, int B, int H, 
 int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq, int Skv, int Sp, int heads, int q_stride,
                        int kv_stride, float scale, f16 *O, int o_stride, hipStream_t s);
 extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups);
+
+// profiling hooks (api.cpp): when on, MFMA kernels are launched with hipExtLaunchKernelGGL start/stop events
+bool ctx_prof_on(void);
+void ctx_prof_events(int klass, hipEvent_t *a, hipEvent_t *b);

@@ -16,37 +16,40 @@
 
 __global__ void k_gn_stats(const f16 *__restrict__ x, int HW, int C, int G, int NS, float *__restrict__ part)
 {
-    __shared__ float s_sum[GN_MAX_GROUPS], s_sq[GN_MAX_GROUPS];
+    // deterministic: per-thread channel partials go to LDS [pl][C][2]; thread g then sums its group's
+    // channels over all pixel lanes in a fixed order (no float atomics anywhere in GroupNorm).
+    extern __shared__ float s_part[];
     const int c8n = C / 8;
     const int PL = blockDim.x / c8n;
     const int b = blockIdx.y, sp = blockIdx.x;
-    for (int i = threadIdx.x; i < G; i += blockDim.x) { s_sum[i] = 0.f; s_sq[i] = 0.f; }
-    __syncthreads();
     const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
     const int per = (HW + NS - 1) / NS;
     const int p0 = sp * per, p1 = min(HW, p0 + per);
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-    if (pl < PL) {
-        const f16 *base = x + ((size_t)b * HW) * C + c8 * 8;
-        for (int p = p0 + pl; p < p1; p += PL) {
-            f16x8 v = *(const f16x8 *)(base + (size_t)p * C);
+    const f16 *base = x + ((size_t)b * HW) * C + c8 * 8;
+    for (int p = p0 + pl; p < p1; p += PL) {
+        f16x8 v = *(const f16x8 *)(base + (size_t)p * C);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
-        }
-        const int cg = C / G;
+        for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int g = (c8 * 8 + j) / cg;
-            atomicAdd(&s_sum[g], s[j]);
-            atomicAdd(&s_sq[g], q[j]);
-        }
+    for (int j = 0; j < 8; ++j) {
+        s_part[((size_t)pl * C + c8 * 8 + j) * 2 + 0] = s[j];
+        s_part[((size_t)pl * C + c8 * 8 + j) * 2 + 1] = q[j];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < G; i += blockDim.x) {
-        part[(((size_t)b * NS + sp) * G + i) * 2 + 0] = s_sum[i];
-        part[(((size_t)b * NS + sp) * G + i) * 2 + 1] = s_sq[i];
+    const int cg = C / G;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float ss = 0.f, qq = 0.f;
+        for (int l = 0; l < PL; ++l)
+            for (int c = g * cg; c < (g + 1) * cg; ++c) {
+                ss += s_part[((size_t)l * C + c) * 2 + 0];
+                qq += s_part[((size_t)l * C + c) * 2 + 1];
+            }
+        part[(((size_t)b * NS + sp) * G + g) * 2 + 0] = ss;
+        part[(((size_t)b * NS + sp) * G + g) * 2 + 1] = qq;
     }
 }
 
@@ -104,7 +107,8 @@ extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const voi
     if (PL < 1) PL = 1;
     int threads = c8n * PL;
     int NS = min(64, max(1, HW / (PL * 4)));
-    hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), 0, s, (const f16 *)x, HW, C, groups, NS, (float *)stats_ws);
+    size_t lds = (size_t)PL * C * 2 * sizeof(float);          // <= 64 KiB (threads <= 1024, 8 channels each)
+    hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), lds, s, (const f16 *)x, HW, C, groups, NS, (float *)stats_ws);
     size_t total = (size_t)HW * c8n;
     int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), 0, s, (const f16 *)x, (const f16 *)gamma, (const f16 *)beta, HW, C,

@@ -192,6 +192,12 @@ int32_t ctx_cfg_plms_step(const float *eps_pair, int64_t n, float guidance, floa
                           const float *coef4, float sample_coeff, float eps_coeff, int32_t mode,
                           float *cur_sample_ws, float *x, ctx_stream_t stream);
 
+/* Live per-kernel timing for bench.py's roofline: between begin and end every MFMA kernel launch (class 0 =
+   GEMM / implicit-GEMM conv, class 1 = attention) is bracketed by dispatch-tight HIP events on ITS stream;
+   end() synchronises them and returns the summed kernel time and the launch count of one class. */
+int32_t ctx_profile_begin(void);
+int32_t ctx_profile_end(int32_t klass, double *total_ms /*host*/, int64_t *count /*host*/);
+
 /* Unit-test support: one 32x32 tile through the MFMA fragment maps the kernels assume.
    which 0: f16 32x32x16 (A[32][16], Bt[32][16]); 1: f32 32x32x2 (A[32][2], Bt[32][2]); C[32][32] f32. */
 int32_t ctx_probe_mfma(int32_t which, const void *A, const void *Bt, float *C, ctx_stream_t stream);
