@@ -17,6 +17,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 #define GK 64          // K-tile
 #define LDS_ROW 72     // f16 per LDS row (64 + 8 pad) = 144 B
@@ -30,6 +31,64 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int r, int h)
+{
+    // ---- epilogue: lane owns row m, registers walk n ---------------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        int m = m0 + wm * 64 + mi * 32 + r;
+        if (m >= a.M) continue;
+        int bidx = a.rowbias ? m / a.rows_per_batch : 0;
+        if (a.epi == 1) {
+            // GEGLU: ni=0 -> value half, ni=1 -> gate half of the same 32 features (packed weight order)
+            int fbase = (n0 + wn * 64) / 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int nn = n0 + wn * 64 + 8 * g + 4 * h;       // packed column of the value half
+                if (nn >= a.N) continue;
+                f16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float xv = acc[mi][0][4 * g + j], gv = acc[mi][1][4 * g + j];
+                    if (a.bias) { xv += (float)a.bias[nn + j]; gv += (float)a.bias[nn + 32 + j]; }
+                    o[j] = (f16)(xv * gelu_erf(gv));
+                }
+                *(f16x4 *)(a.out + (size_t)m * a.ldc + fbase + 8 * g + 4 * h) = o;
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int nn = n0 + wn * 64 + ni * 32 + 8 * g + 4 * h;
+                    if (nn >= a.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * g + j];
+                    if (a.bias) {
+                        f16x4 b = *(const f16x4 *)(a.bias + nn);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
+                    }
+                    if (a.rowbias) {
+                        f16x4 b = *(const f16x4 *)(a.rowbias + (size_t)bidx * a.ldrb + nn);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
+                    }
+                    if (a.residual) {
+                        f16x4 b = *(const f16x4 *)(a.residual + (size_t)m * a.ldr + nn);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
+                    }
+                    f16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
+                    *(f16x4 *)(a.out + (size_t)m * a.ldc + nn) = o;
+                }
+        }
+    }
+}
 
 template <int WM, int WN, bool CONV>
 __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs a)
@@ -139,59 +198,288 @@ __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs a)
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns row m, registers walk n ---------------------------------------------
+    gemm_epilogue(a, acc, m0, n0, wm, wn, r, h);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (default): tiles go global -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave
+// instruction, no staging VGPRs), single LDS buffer, two barriers per K-tile.  LDS use is 32-40 KiB and the
+// register budget ~110, so 3-4 workgroups share a CU and overlap each other's load / MFMA phases.
+// The LDS image is lane-linear ([rows][128 B]); bank conflicts are avoided by XOR-swizzling the 16-byte chunk
+// index with (row>>1)&7 on the per-lane SOURCE address and again on the fragment read.
+// Padding / out-of-range rows read from a zero page.
+__device__ __attribute__((aligned(16))) f16 g_zero_page[64];
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int WM, int WN, bool CONV>
+__global__ __launch_bounds__(256) void k_gemm_glds(GemmArgs a)
+{
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int XI = BM / 32, WI = BN / 32;      // LDS-DMA instructions per wave per K-tile
+    extern __shared__ __attribute__((aligned(16))) f16 smem[];
+    f16 *Xs = smem;                                 // [BM][64]
+    f16 *Ws = smem + BM * 64;                       // [BN][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_remap(blockIdx.x, a.ntm * a.ntn);
+    const int tile_n = bid % a.ntn, tile_m = bid / a.ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int lr = lane >> 3, pc = lane & 7;        // row within the instruction's 8 rows, physical chunk
+
+    int xoff[XI], xoy[XI], xox[XI], xlc[XI];
+    bool xok[XI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        int m = m0 + wm * 64 + mi * 32 + r;
-        if (m >= a.M) continue;
-        int bidx = a.rowbias ? m / a.rows_per_batch : 0;
-        if (a.epi == 1) {
-            // GEGLU: ni=0 -> value half, ni=1 -> gate half of the same 32 features (packed weight order)
-            int fbase = (n0 + wn * 64) / 2;
+    for (int i = 0; i < XI; ++i) {
+        int row = 8 * (wave + 4 * i) + lr;
+        int m = m0 + row;
+        xlc[i] = (pc ^ ((row >> 1) & 7)) * 8;       // logical chunk (in f16) this lane must fetch
+        xok[i] = m < a.M;
+        if (CONV) {
+            int hw = a.Ho * a.Wo;
+            int b = m / hw, p = m - b * hw;
+            int oy = p / a.Wo, ox = p - oy * a.Wo;
+            xoy[i] = oy * a.stride; xox[i] = ox * a.stride;
+            xoff[i] = b * a.H * a.W * a.Cin;
+        } else {
+            xoff[i] = m * a.K; xoy[i] = 0; xox[i] = 0;
+        }
+    }
+    int woff[WI], wlc[WI];
+    bool wok[WI];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int nn = n0 + wn * 64 + 8 * g + 4 * h;       // packed column of the value half
-                if (nn >= a.N) continue;
-                f16x4 o;
+    for (int i = 0; i < WI; ++i) {
+        int row = 8 * (wave + 4 * i) + lr;
+        wlc[i] = (pc ^ ((row >> 1) & 7)) * 8;
+        wok[i] = (n0 + row) < a.N;
+        woff[i] = (n0 + row) * a.K;
+    }
+
+    f32x16 acc[2][2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float xv = acc[mi][0][4 * g + j], gv = acc[mi][1][4 * g + j];
-                    if (a.bias) { xv += (float)a.bias[nn + j]; gv += (float)a.bias[nn + 32 + j]; }
-                    o[j] = (f16)(xv * gelu_erf(gv));
-                }
-                *(f16x4 *)(a.out + (size_t)m * a.ldc + fbase + 8 * g + 4 * h) = o;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int swz = (r >> 1) & 7;
+    const f16 *xb = Xs + (wm * 64 + r) * 64;
+    const f16 *wb = Ws + (wn * 64 + r) * 64;
+    const int nk = a.K / GK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int k0 = kt * GK;
+        if (CONV) {
+            int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+            int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int Hv = a.H << a.ups, Wv = a.W << a.ups;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                int iy = xoy[i] + dy, ix = xox[i] + dx;
+                bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+                const f16 *src = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 + xlc[i] : g_zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (wave + 4 * i) * 512), 16, 0, 0);
             }
         } else {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const f16 *src = xok[i] ? a.X + xoff[i] + k0 + xlc[i] : g_zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (wave + 4 * i) * 512), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const f16 *src = wok[i] ? a.Wt + woff[i] + k0 + wlc[i] : g_zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ws + (wave + 4 * i) * 512), 16, 0, 0);
+        }
+        __syncthreads();                            // vmcnt(0) + barrier: the tile has landed
+#pragma unroll
+        for (int ks = 0; ks < GK / 16; ++ks) {
+            const int pch = ((2 * ks + h) ^ swz) * 8;
+            f16x8 xf0 = *(const f16x8 *)(xb + pch);
+            f16x8 xf1 = *(const f16x8 *)(xb + 32 * 64 + pch);
+            f16x8 wf0 = *(const f16x8 *)(wb + pch);
+            f16x8 wf1 = *(const f16x8 *)(wb + 32 * 64 + pch);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();                            // everyone is done reading before the next tile overwrites
+    }
+    gemm_epilogue(a, acc, m0, n0, wm, wn, r, h);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined LDS-DMA variant: K-stages of 32, ring of NS stages, prefetch distance NS-1, ONE raw s_barrier per
+// stage and a counted s_waitcnt vmcnt so the newer stages' DMA stays in flight across the barrier.
+//   iteration kt:  vmcnt((NS-2)*G)  -> this wave's pieces of stage kt have landed
+//                  s_barrier        -> everybody's pieces landed AND everybody finished stage kt-1
+//                  issue stage kt+NS-1 into the buffer stage kt-1 used
+//                  8 x MFMA on stage kt
+// 64-byte LDS rows ([rows][32 f16]), chunk swizzle c ^ ((row>>2)&3) applied on the DMA source address and on the
+// fragment read (conflict-free ds_read_b128 under the 64-bank / 16-lane-group rule).
+#define PK 32
+template <int WM, int WN, bool CONV, int NS>
+__global__ __launch_bounds__(256) void k_gemm_pipe(GemmArgs a)
+{
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int XI = BM / 64, WI = BN / 64;       // DMA pieces per wave per stage (16 rows x 64 B each)
+    constexpr int G = XI + WI;
+    constexpr int STAGE = (BM + BN) * PK;           // f16 per stage
+    extern __shared__ __attribute__((aligned(16))) f16 smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_remap(blockIdx.x, a.ntm * a.ntn);
+    const int tile_n = bid % a.ntn, tile_m = bid / a.ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int lr = lane >> 2, pc = lane & 3;        // row within the piece's 16 rows, physical 16-B chunk
+
+    int xoff[XI], xoy[XI], xox[XI], xlc[XI];
+    bool xok[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        int row = 16 * (wave + 4 * i) + lr;
+        int m = m0 + row;
+        xlc[i] = (pc ^ ((row >> 2) & 3)) * 8;
+        xok[i] = m < a.M;
+        if (CONV) {
+            int hw = a.Ho * a.Wo;
+            int b = m / hw, p = m - b * hw;
+            int oy = p / a.Wo, ox = p - oy * a.Wo;
+            xoy[i] = oy * a.stride; xox[i] = ox * a.stride;
+            xoff[i] = b * a.H * a.W * a.Cin;
+        } else {
+            xoff[i] = m * a.K; xoy[i] = 0; xox[i] = 0;
+        }
+    }
+    int woff[WI], wlc[WI];
+    bool wok[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        int row = 16 * (wave + 4 * i) + lr;
+        wlc[i] = (pc ^ ((row >> 2) & 3)) * 8;
+        wok[i] = (n0 + row) < a.N;
+        woff[i] = (n0 + row) * a.K;
+    }
+    const int nk_all = a.K / PK;
+    const int kbeg = (int)((long)nk_all * blockIdx.y / a.splitk);
+    const int nk = (int)((long)nk_all * (blockIdx.y + 1) / a.splitk) - kbeg;
+    auto stage = [&](int kt) {
+        f16 *Xs = smem + (kt % NS) * STAGE;
+        f16 *Ws = Xs + BM * PK;
+        const int k0 = (kbeg + kt) * PK;
+        if (CONV) {
+            int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+            int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int Hv = a.H << a.ups, Wv = a.W << a.ups;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                int iy = xoy[i] + dy, ix = xox[i] + dx;
+                bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+                const f16 *src = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 + xlc[i] : g_zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (wave + 4 * i) * 512), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const f16 *src = xok[i] ? a.X + xoff[i] + k0 + xlc[i] : g_zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (wave + 4 * i) * 512), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const f16 *src = wok[i] ? a.Wt + woff[i] + k0 + wlc[i] : g_zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ws + (wave + 4 * i) * 512), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // prologue: NS-1 stages in flight (issue empty groups past the end so the vmcnt arithmetic stays uniform)
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nk) stage(p);
+    const int swz = (r >> 2) & 3;
+    const int xrow = (wm * 64 + r) * PK, wrow = BM * PK + (wn * 64 + r) * PK;
+    for (int kt = 0; kt < nk; ++kt) {
+        // pieces still allowed in flight after this wait: those of stages kt+1 .. kt+NS-2 that exist
+        int newer = nk - 1 - kt;
+        if (newer > NS - 2) newer = NS - 2;
+        if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) stage(kt + NS - 1);
+        const f16 *sb = smem + (kt % NS) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < PK / 16; ++ks) {
+            const int pch = ((2 * ks + h) ^ swz) * 8;
+            f16x8 xf0 = *(const f16x8 *)(sb + xrow + pch);
+            f16x8 xf1 = *(const f16x8 *)(sb + xrow + 32 * PK + pch);
+            f16x8 wf0 = *(const f16x8 *)(sb + wrow + pch);
+            f16x8 wf1 = *(const f16x8 *)(sb + wrow + 32 * PK + pch);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf1, acc[1][1], 0, 0, 0);
+        }
+    }
+    if (a.splitk > 1) {
+        float *pb = a.part + (size_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            int m = m0 + wm * 64 + mi * 32 + r;
+            if (m >= a.M) continue;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     int nn = n0 + wn * 64 + ni * 32 + 8 * g + 4 * h;
                     if (nn >= a.N) continue;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * g + j];
-                    if (a.bias) {
-                        f16x4 b = *(const f16x4 *)(a.bias + nn);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
-                    }
-                    if (a.rowbias) {
-                        f16x4 b = *(const f16x4 *)(a.rowbias + (size_t)bidx * a.ldrb + nn);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
-                    }
-                    if (a.residual) {
-                        f16x4 b = *(const f16x4 *)(a.residual + (size_t)m * a.ldr + nn);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
-                    }
-                    f16x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
-                    *(f16x4 *)(a.out + (size_t)m * a.ldc + nn) = o;
+                    f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                    *(f32x4 *)(pb + (size_t)m * a.N + nn) = v;
                 }
         }
+        return;
+    }
+    gemm_epilogue(a, acc, m0, n0, wm, wn, r, h);
+}
+
+// Split-K second pass: out = sum_s part[s] (+bias)(+rowbias)(+residual) -> f16.  Fixed summation order.
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a)
+{
+    const int n4 = a.N / 4;
+    const size_t total = (size_t)a.M * n4, MN = (size_t)a.M * a.N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int m = (int)(i / n4), nn = (int)(i % n4) * 4;
+        f32x4 v = *(const f32x4 *)(a.part + (size_t)m * a.N + nn);
+        for (int sidx = 1; sidx < a.splitk; ++sidx) {
+            f32x4 p = *(const f32x4 *)(a.part + sidx * MN + (size_t)m * a.N + nn);
+            v += p;
+        }
+        if (a.bias) { f16x4 b = *(const f16x4 *)(a.bias + nn); for (int j = 0; j < 4; ++j) v[j] += (float)b[j]; }
+        if (a.rowbias) {
+            f16x4 b = *(const f16x4 *)(a.rowbias + (size_t)(m / a.rows_per_batch) * a.ldrb + nn);
+            for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
+        }
+        if (a.residual) { f16x4 b = *(const f16x4 *)(a.residual + (size_t)m * a.ldr + nn); for (int j = 0; j < 4; ++j) v[j] += (float)b[j]; }
+        f16x4 o;
+        for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
+        *(f16x4 *)(a.out + (size_t)m * a.ldc + nn) = o;
     }
 }
 
@@ -201,6 +489,45 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
     constexpr int BM = 64 * WM, BN = 64 * WN;
     a.ntm = cdiv(a.M, BM);
     a.ntn = cdiv(a.N, BN);
+    static int impl = -1;
+    if (impl < 0) { const char *e = getenv("CTX_GEMM_IMPL"); impl = e ? atoi(e) : 2; }
+    if (a.splitk < 1 || !a.part || impl != 2) a.splitk = 1;
+    if (impl == 2) {
+        constexpr int NS = 4;
+        size_t lds = (size_t)NS * (BM + BN) * PK * sizeof(f16);
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void *)k_gemm_pipe<WM, WN, CONV, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr2 = true;
+        }
+        if (ctx_prof_on()) {
+            hipEvent_t e0, e1;
+            ctx_prof_events(0, &e0, &e1);
+            hipExtLaunchKernelGGL((k_gemm_pipe<WM, WN, CONV, NS>), dim3(a.ntm * a.ntn, a.splitk), dim3(256), lds, s, e0, e1, 0, a);
+        } else
+            hipLaunchKernelGGL((k_gemm_pipe<WM, WN, CONV, NS>), dim3(a.ntm * a.ntn, a.splitk), dim3(256), lds, s, a);
+        if (a.splitk > 1) {
+            size_t total = (size_t)a.M * (a.N / 4);
+            unsigned nb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+            if (ctx_prof_on()) {
+                hipEvent_t e0, e1;
+                ctx_prof_events(0, &e0, &e1);
+                hipExtLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, e0, e1, 0, a);
+            } else
+                hipLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, a);
+        }
+        return;
+    }
+    if (impl == 1) {
+        size_t lds = (size_t)(BM + BN) * 64 * sizeof(f16);
+        if (ctx_prof_on()) {
+            hipEvent_t e0, e1;
+            ctx_prof_events(0, &e0, &e1);
+            hipExtLaunchKernelGGL((k_gemm_glds<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, e0, e1, 0, a);
+        } else
+            hipLaunchKernelGGL((k_gemm_glds<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, a);
+        return;
+    }
     size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(f16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -213,6 +540,21 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
         hipExtLaunchKernelGGL((k_gemm_f16<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, e0, e1, 0, a);
     } else
         hipLaunchKernelGGL((k_gemm_f16<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, a);
+}
+
+int ctx_gemm_pick_split(int M, int N, int K, int epi)
+{
+    static int en = -1;
+    if (en < 0) { const char *e = getenv("CTX_SPLITK"); en = e ? atoi(e) : 1; }
+    if (!en || epi != 0 || N % 4) return 1;
+    bool wide = (N % 128 == 0);
+    int tiles = wide ? cdiv(M, 128) * cdiv(N, 128) : cdiv(M, 256) * cdiv(N, 64);
+    if (tiles >= 200) return 1;
+    int S = 640 / tiles;                       // aim at ~2.5 workgroups per CU
+    int maxS = (K / PK) / 8;                   // keep >= 8 stages per split
+    if (S > maxS) S = maxS;
+    if (S > 32) S = 32;
+    return S < 2 ? 1 : S;
 }
 
 // Tile choice: 128x128 when N is a multiple of 128 (no masked columns), else 256x64.

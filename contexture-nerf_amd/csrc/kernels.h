@@ -17,9 +17,13 @@ struct GemmArgs {
     // conv
     int H, W, Cin, Ho, Wo, stride, ups;
     int ntm, ntn;
+    int splitk;            // >1: grid.y = splitk, fp32 partials [splitk][M][N] go to `part`
+    float *part;
 };
 
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s);
+// split-K factor the dispatcher would use for this problem (1 = none); caller provides a.part = S*M*N floats
+int ctx_gemm_pick_split(int M, int N, int K, int epi);
 int ctx_gemv_f16(const f16 *x, const f16 *w, const f16 *bias, int Bm, int N, int K, int silu_in, int silu_out, f16 *out, hipStream_t s);
 int ctx_concat_f16(const f16 *a, const f16 *b, int64_t M, int Ca, int Cb, f16 *y, hipStream_t s);
 int ctx_transpose_v_f16(const f16 *v, int B, int S, int ld, int heads, int Sp, f16 *vt, hipStream_t s);

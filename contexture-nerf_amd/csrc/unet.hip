@@ -308,7 +308,11 @@ static void op_gemm(ctx_unet *u, const f16 *X, size_t w, size_t bias, bool has_b
     a.X = X; a.Wt = u->W + w; a.bias = has_bias ? u->W + bias : nullptr; a.residual = res; a.out = out;
     a.M = M; a.N = N; a.K = K; a.ldc = epi == 1 ? N / 2 : N; a.ldr = N; a.rows_per_batch = 1; a.ldrb = N; a.epi = epi;
     note(u, 0, 2.0 * M * N * K);
+    size_t mark = u->top;
+    a.splitk = ctx_gemm_pick_split(M, N, K, epi);
+    if (a.splitk > 1) a.part = (float *)u->alloc((size_t)a.splitk * M * N * 4);
     RUN(ctx_gemm_dispatch(a, false, u->s));
+    u->top = mark;
 }
 static void op_conv(ctx_unet *u, const f16 *x, size_t w, size_t bias, const f16 *rowbias, int ldrb, const f16 *res, int B, int H,
                     int W, int Cin, int Cout, int stride, int ups, f16 *out)
@@ -320,7 +324,11 @@ static void op_conv(ctx_unet *u, const f16 *x, size_t w, size_t bias, const f16 
     a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Ho * a.Wo; a.ldrb = ldrb;
     a.H = H; a.W = W; a.Cin = Cin; a.stride = stride; a.ups = ups;
     note(u, 0, 2.0 * a.M * a.N * a.K);
+    size_t mark = u->top;
+    a.splitk = ctx_gemm_pick_split(a.M, a.N, a.K, 0);
+    if (a.splitk > 1) a.part = (float *)u->alloc((size_t)a.splitk * a.M * a.N * 4);
     RUN(ctx_gemm_dispatch(a, true, u->s));
+    u->top = mark;
 }
 static void op_gn(ctx_unet *u, const f16 *x, size_t g, size_t b, int B, int HW, int C, float eps, int silu, f16 *y, void *stats)
 {

@@ -1,0 +1,126 @@
+"""StableDiffusion: mirror of the live members of src/stable_diffusion_depth.py
+(`__init__` :27-106, `get_text_embeds` :222-244, `img2img_step` :284-578 incl. inner `sample`,
+`encode_imgs`/`decode_latents` :971-990, `get_timesteps` :992-999) with the denoise loop on the HIP UNet engine.
+
+Offline facts: no SD2 weights / tokenizer / diffusers => the UNet is the SD2-depth ARCHITECTURE with
+seeded random-init weights (or a local safetensors state_dict passed as `unet_state_dict`), text embeddings come
+from a caller-supplied encoder or are seeded random [2,77,1024], and the VAE ("next") must be
+supplied by the caller; without one `decode_latents` returns a fixed linear latent->RGB preview, flagged as such.
+
+Additions over the reference: `image_size` is a parameter (the reference hard-wires 512, :519) because
+BASELINE.json's configs run 256^2 / 512^2 / 768^2.
+"""
+import torch
+import torch.nn.functional as F
+from . import _lib as L
+from .scheduler import PNDMScheduler
+from .unet import UNet2DConditionModel
+from .utils import seed_everything
+
+# 4->3 linear read-out commonly used to preview SD latents (NOT the VAE; parity-irrelevant placeholder)
+_PREVIEW = torch.tensor([[0.298, 0.207, 0.208], [0.187, 0.286, 0.173], [-0.158, 0.189, 0.264], [-0.184, -0.271, -0.473]])
+
+
+class StableDiffusion:
+    def __init__(self, device, model_name='stabilityai/stable-diffusion-2-depth', concept_name=None, concept_path=None,
+                 latent_mode=True, min_timestep=0.02, max_timestep=0.98, no_noise=False, use_inpaint=False,
+                 second_model_type=None, guess_mode=False, unet=None, unet_state_dict=None, vae=None, text_encoder=None,
+                 seed=0):
+        if second_model_type not in (None,):
+            raise L.CtxError(f"second_model_type={second_model_type!r}: dead branch in the reference (needs src/zero123), not built")
+        self.device = device
+        self.latent_mode = latent_mode
+        self.no_noise = no_noise
+        self.use_inpaint = False                      # never activates in the reference (paint_step stays 0, trainer.py:1048)
+        self.second_model_type = second_model_type
+        self.num_train_timesteps = 1000
+        self.min_step = int(self.num_train_timesteps * min_timestep)
+        self.max_step = int(self.num_train_timesteps * max_timestep)
+        self.unet = unet if unet is not None else UNet2DConditionModel(device=device, seed=seed, init=unet_state_dict is None)
+        if unet_state_dict is not None:
+            self.unet.load_state_dict(unet_state_dict)
+        self.vae = vae
+        self.text_encoder = text_encoder
+        self.scheduler = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                       num_train_timesteps=self.num_train_timesteps, steps_offset=1, skip_prk_steps=True)
+        self.alphas = self.scheduler.alphas_cumprod.to(self.device)
+
+    def get_text_embeds(self, prompt, negative_prompt=None, seed=0):
+        """-> cat([uncond, cond]) [2,77,1024].  With no encoder (offline) a seeded random embedding stands in."""
+        if self.text_encoder is not None:
+            return self.text_encoder(prompt, negative_prompt)
+        g = torch.Generator().manual_seed(hash((tuple(prompt), seed)) % (2 ** 31))
+        return torch.randn(2, 77, self.unet.config['cross_attention_dim'], generator=g).to(self.device)
+
+    def get_timesteps(self, num_inference_steps, strength):
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        return self.scheduler.timesteps[t_start:], num_inference_steps - t_start
+
+    def encode_imgs(self, imgs):
+        if self.vae is None:
+            raise L.CtxError("encode_imgs: no VAE supplied (AutoencoderKL is SURVEY §8f n2, not built this round)")
+        imgs = 2 * imgs - 1
+        return self.vae.encode(imgs).latent_dist.sample() * 0.18215
+
+    def decode_latents(self, latents):
+        latents = 1 / 0.18215 * latents
+        if self.vae is None:                          # preview only — see module docstring
+            rgb = torch.einsum('bchw,cd->bdhw', latents * 0.18215, _PREVIEW.to(latents.device))
+            return (F.interpolate(rgb, scale_factor=8, mode='nearest') / 2 + 0.5).clamp(0, 1)
+        with torch.no_grad():
+            imgs = self.vae.decode(latents).sample
+        return (imgs / 2 + 0.5).clamp(0, 1)
+
+    def img2img_step(self, text_embeddings, inputs, original_depth_mask, guidance_scale=100, strength=0.5,
+                     num_inference_steps=50, update_mask=None, latent_mode=False, fixed_seed=None, intermediate_vis=False,
+                     view_dir=None, front_image=None, phi=None, theta=None, condition_guidance_scales=None, image_size=512):
+        intermediate_results = []
+
+        def sample(latents, depth_mask, strength, num_inference_steps, update_mask=None, masked_latents=None):
+            self.scheduler.set_timesteps(num_inference_steps)
+            shape = (text_embeddings.shape[0] // 2, self.unet.in_channels - 1, depth_mask.shape[2], depth_mask.shape[3])
+            if latents is None:
+                latents = torch.randn(shape, device=self.device)
+                timesteps = self.scheduler.timesteps
+            else:
+                timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength)
+                latent_timestep = timesteps[:1]
+                if fixed_seed is not None:
+                    seed_everything(fixed_seed)
+                noise = torch.randn_like(latents)
+                if update_mask is not None:
+                    latents = torch.randn(shape, device=self.device)      # gt_latents are never blended (blend commented out, :382)
+                else:
+                    latents = self.scheduler.add_noise(latents, noise, latent_timestep)
+            depth2 = torch.cat([depth_mask] * 2)
+            for i, t in enumerate(timesteps):
+                latent_model_input = torch.cat([latents] * 2)
+                latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+                x = torch.cat([latent_model_input, depth2], dim=1)
+                noise_pred = self.unet(x, float(t), encoder_hidden_states=text_embeddings)['sample']
+                latents = self.scheduler.step_cfg(noise_pred, guidance_scale, int(t), latents)['prev_sample']
+            return latents
+
+        depth_mask = F.interpolate(original_depth_mask, size=(image_size // 8, image_size // 8), mode='bicubic', align_corners=False)
+        if inputs is None:
+            latents = None
+        elif latent_mode:
+            latents = inputs
+        elif self.vae is None:
+            # the encoded render only matters when update_mask is None (it is discarded otherwise, see sample()):
+            # the reference's live call always passes update_mask, so a zero latent of the right shape is equivalent
+            latents = torch.zeros(inputs.shape[0], self.unet.in_channels - 1, image_size // 8, image_size // 8, device=self.device)
+        else:
+            pred_rgb_small = F.interpolate(inputs, (image_size, image_size), mode='bilinear', align_corners=False)
+            latents = self.encode_imgs(pred_rgb_small)
+        if update_mask is not None:
+            update_mask = F.interpolate(update_mask, (image_size // 8, image_size // 8), mode='nearest')
+        depth_mask = 2.0 * (depth_mask - depth_mask.min()) / (depth_mask.max() - depth_mask.min()) - 1.0
+        with torch.no_grad():
+            target_latents = sample(latents, depth_mask, strength=strength, num_inference_steps=num_inference_steps,
+                                    update_mask=update_mask)
+            target_rgb = self.decode_latents(target_latents)
+        if latent_mode:
+            return target_rgb, target_latents
+        return target_rgb, intermediate_results

@@ -1,0 +1,30 @@
+"""`python -m scripts.run_texture --config_path=configs/text_guided/<x>.yaml [--a.b=value]` — the reference's
+documented entry (README.md:67; its file is scripts/run_contexture.py:1-17).  Runs the per-view paint path on the
+HIP kernels; under torchrun the views are sharded one per GPU."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from contexture_nerf_amd import config as cfgmod  # noqa: E402
+from contexture_nerf_amd.trainer import ConTEXTure  # noqa: E402
+from contexture_nerf_amd.stable_diffusion_depth import StableDiffusion  # noqa: E402
+
+
+@cfgmod.wrap()
+def main(cfg: cfgmod.TrainConfig):
+    trainer = ConTEXTure(cfg)
+    trainer.diffusion = StableDiffusion(trainer.device, model_name=cfg.guide.diffusion_name, seed=cfg.optim.seed)
+    exp = cfg.log.exp_dir
+    os.makedirs(exp, exist_ok=True)
+    cfgmod.dump(cfg, os.path.join(exp, 'config.yaml'))
+    if cfg.log.eval_only:
+        raise SystemExit("eval_only: full_eval is out of scope of this build (SURVEY §3.5)")
+    atlas, coverage = trainer.paint()
+    if trainer.rank == 0:
+        torch.save({'atlas': atlas.cpu(), 'coverage': coverage.cpu()}, os.path.join(exp, 'atlas.pt'))
+        print(f"painted {len(trainer.train_views)} views -> {exp}/atlas.pt  coverage {float((coverage > 0).float().mean()):.3f}")
+
+
+if __name__ == '__main__':
+    main()

@@ -27,7 +27,7 @@ def golden_meta():
 
 @pytest.fixture(scope="session")
 def meshes():
-    return np.load(os.path.join(GOLDEN, "meshes.npz"))
+    return np.load(os.path.join(ROOT, "shapes", "meshes.npz"))
 
 
 @pytest.fixture(scope="session")

@@ -225,8 +225,8 @@ def make_meshes():
         out[name + '_v'] = v; out[name + '_f'] = f.astype(np.int32)
         out[name + '_vt'] = vt; out[name + '_ft'] = ft.astype(np.int32)
         print(name, v.shape, f.shape, vt.shape, int(ft.min()) if ft.size else None)
-    np.savez_compressed(os.path.join(HERE, 'meshes.npz'), **out)
-    print('meshes.npz', os.path.getsize(os.path.join(HERE, 'meshes.npz')))
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'shapes', 'meshes.npz'), **out)
+    print('meshes.npz', os.path.getsize(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'shapes', 'meshes.npz')))
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'meshes':

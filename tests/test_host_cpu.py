@@ -1,0 +1,92 @@
+"""CPU: host-side mirrors (crop box, grid split/merge, pose lists, view direction, DreamTime table, scale helpers,
+config surface, OBJ reader, sample_pdf / ndc_rays host logic) against the reference's own outputs in tests/golden."""
+import os
+import numpy as np
+import torch
+from contexture_nerf_amd import utils as U, views_dataset as VD, config as CFG, kal
+from contexture_nerf_amd import run_nerf_helpers as rnh
+from contexture_nerf_amd.mesh import Mesh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_crop_boxes_and_grid(golden, golden_meta):
+    for spec, box in zip(golden_meta['crop_specs'], golden_meta['crop_boxes']):
+        h, w, y0, y1, x0, x1 = spec
+        m = torch.zeros(h, w); m[y0:y1, x0:x1] = 1
+        assert list(U.get_nonzero_region_tuple(m)) == box
+    grid = torch.arange(1 * 4 * 120 * 80, dtype=torch.float32).reshape(1, 4, 120, 80)
+    t = U.split_3x2_grid_to_tensor_with_6_elements(grid, 40)
+    assert t.shape == (6, 4, 40, 40)
+    np.testing.assert_allclose(t.reshape(6, -1).sum(1).numpy(), golden['grid_tiles_sum'])
+    assert np.array_equal(t[:, 0, 0, 0].numpy(), golden['grid_tiles_corner'])
+    assert torch.equal(U.merge_tensor_with_6_elements_to_3x2_grid(t, 40), grid)
+
+
+def test_pose_lists_and_view_direction(golden, golden_meta):
+    rc = CFG.RenderConfig()
+    for name, cls in (('zero123plus', VD.Zero123PlusDataset), ('multiview', VD.MultiviewDataset)):
+        rows = [{'dir': int(d['dir'][0]), 'theta': float(d['theta']), 'phi': float(d['phi']), 'radius': float(d['radius']),
+                 'base_theta': float(d['base_theta'])} for d in cls(rc, 'cpu')]
+        assert rows == golden_meta['views_' + name]
+    d = U.get_view_direction(torch.tensor(golden['viewdir_theta']), torch.tensor(golden['viewdir_phi']), np.deg2rad(40.0), np.deg2rad(70.0))
+    assert np.array_equal(d.numpy(), golden['viewdir'])
+
+
+def test_dreamtime_and_scales(golden):
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    ds = U.DreamTimeScheduler(torch.cumprod(1.0 - betas, 0), 5000, m=500, s=125)
+    assert [ds.get_t(int(i)) for i in golden['dreamtime_i']] == list(golden['dreamtime_t'])
+    z = torch.tensor(golden['scale_in'])
+    for fn in ('scale_latents', 'unscale_latents', 'scale_image', 'unscale_image'):
+        np.testing.assert_allclose(getattr(U, fn)(z).numpy(), golden[fn], rtol=1e-6, atol=1e-7)
+
+
+def test_config_defaults_and_cli(golden_meta, tmp_path):
+    for cls, key in ((CFG.RenderConfig, 'cfg_render'), (CFG.OptimConfig, 'cfg_optim')):
+        got = {k: v for k, v in vars(cls()).items()}
+        for k, v in golden_meta[key].items():
+            assert got[k] == v or list(map(list, got[k])) == v, (k, got[k], v)
+    g = vars(CFG.GuideConfig())
+    for k, v in golden_meta['cfg_guide'].items():
+        if v != '<required>':
+            assert str(g[k]) == str(v), (k, g[k], v)
+    l = vars(CFG.LogConfig())
+    for k, v in golden_meta['cfg_log'].items():
+        if v != '<required>':
+            assert str(l[k]).rstrip('/') == str(v).rstrip('/'), k
+    cfg = CFG.parse(CFG.TrainConfig, [f'--config_path={ROOT}/configs/text_guided/nascar.yaml', '--optim.seed=5', '--guide.guidance_scale=7.5'])
+    assert cfg.guide.shape_path == 'shapes/nascar.obj' and cfg.optim.seed == 5 and cfg.guide.guidance_scale == 7.5
+    try:
+        CFG.parse(CFG.TrainConfig, ['--guide.guidance_scale_crossattn=1'])
+        assert False, "unknown key must raise like pyrallis does"
+    except KeyError:
+        pass
+    CFG.dump(cfg, tmp_path / 'c.yaml')
+    cfg2 = CFG.parse(CFG.TrainConfig, [f'--config_path={tmp_path}/c.yaml'])
+    assert cfg2.guide.text == cfg.guide.text and cfg2.render.views_after == cfg.render.views_after
+
+
+def test_mesh_normalise_and_obj_reader(golden, tmp_path):
+    v = torch.tensor(golden['mesh_v']); f = torch.tensor(golden['mesh_f'])
+    n, a = Mesh.calculate_face_normals(v, f)
+    np.testing.assert_allclose(n.numpy(), golden['mesh_fn'], rtol=1e-6, atol=1e-7)
+    m = Mesh(arrays=(golden['mesh_v'], golden['mesh_f'], np.zeros((0, 2), np.float32), np.zeros((0, 3), np.int64)))
+    np.testing.assert_allclose(m.normalize_mesh(inplace=True, target_scale=0.6, dy=0.25).vertices.numpy(), golden['mesh_v_norm'], rtol=1e-6, atol=1e-6)
+    p = tmp_path / 'q.obj'
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\nf -4//1 -3//1 -2//1\n")
+    mm = kal.io.obj.import_mesh(str(p))
+    assert mm.faces.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2]]
+    assert mm.face_uvs_idx.tolist() == [[0, 1, 2], [0, 2, 3], [-1, -1, -1]]
+    big = Mesh('shapes/nascar.obj', 'cpu')
+    assert big.vertices.shape == (3750, 3) and big.faces.shape == (7500, 3)
+
+
+def test_sampling_host_logic(golden):
+    s = rnh.sample_pdf(torch.tensor(golden['pdf_bins']), torch.tensor(golden['pdf_w']), 24, det=True)
+    np.testing.assert_allclose(s.numpy(), golden['pdf_det'], rtol=1e-6, atol=1e-6)
+    s = rnh.sample_pdf(torch.tensor(golden['pdf_bins']), torch.tensor(golden['pdf_w']), 24, det=False, pytest=True)
+    np.testing.assert_allclose(s.numpy(), golden['pdf_pytest'], rtol=1e-6, atol=1e-6)
+    no, nd = rnh.ndc_rays(6, 8, 5.0, 1.0, torch.tensor(golden['rays_o']), torch.tensor(golden['rays_d']))
+    np.testing.assert_allclose(no.numpy(), golden['ndc_o'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(nd.numpy(), golden['ndc_d'], rtol=1e-6, atol=1e-6)

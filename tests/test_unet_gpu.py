@@ -158,7 +158,8 @@ def test_cfg_plms_scheduler(dev):
             pair = torch.randn(2, 4, 8, 8, generator=g)
             xd = sch.step_cfg(pair.to(dev), 10.0, int(t), xd)['prev_sample']
             xr = ref.step(cfg(pair.numpy(), 10.0), t, xr)
-            np.testing.assert_allclose(xd.cpu().numpy(), xr, rtol=2e-5, atol=1e-4)   # |x| reaches ~30 at guidance 10
+            d = np.linalg.norm(xd.cpu().numpy() - xr) / np.linalg.norm(xr)
+            assert d < 2e-6, d      # float32 op-order differences only (|x| grows to ~1e2 at guidance 10)
     # diffusers-shaped step() == step_cfg with identical halves; add_noise
     sch, ref = PNDMScheduler(), PNDMRef()
     sch.set_timesteps(5); ref.set_timesteps(5)
