@@ -87,36 +87,42 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a)
             }
         }
         // ---- online softmax over this lane's query column ------------------------------------------
-        float mx = -INFINITY;
+        // raw scores stay unscaled; p = exp2(s*c - m) is one FMA + one v_exp_f32 per element (c = scale*log2 e)
+        const float c = a.scale_log2e;
+        if (k0 + AT_KB > a.Skv) {                    // only the last tile can hold padded keys
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                int key = k0 + kb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                float v = s[kb][q] * a.scale_log2e;
-                if (key >= a.Skv) v = -INFINITY;
-                s[kb][q] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                for (int q = 0; q < 16; ++q) {
+                    int key = k0 + kb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (key >= a.Skv) s[kb][q] = -INFINITY;
+                }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) mx = fmaxf(mx, fmaxf(s[0][q], s[1][q]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
         float m_new = fmaxf(m_run, mx);
-        float alpha = exp2f(m_run - m_new);          // m_run = -inf on the first tile -> 0
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                float p = exp2f(s[kb][q] - m_new);
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][q], c, -m_new));
                 s[kb][q] = p;
                 psum += p;
             }
         psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
+        if (__any(m_new != m_run)) {                 // wave-uniform: rescale only when some row's max moved
+            float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) o[d][q] *= alpha;
+        }
+        l_run += psum;
         m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) o[d][q] *= alpha;
 
         // ---- O^T += V^T . P^T --------------------------------------------------------------------------
         // P^T as B operand of k-step st (16 keys) of block kb: elements j = registers 8*st + j, whose key is

@@ -30,7 +30,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-GELU (erf form) with a branch-free erf: Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7 (far below fp16 resolution)
+__device__ __forceinline__ float fast_erf(float x)
+{
+    float ax = __builtin_fabsf(x);
+    float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    float e = 1.0f - p * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return __builtin_copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int r, int h)
 {
@@ -325,13 +334,16 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmArgs a)
 // 64-byte LDS rows ([rows][32 f16]), chunk swizzle c ^ ((row>>2)&3) applied on the DMA source address and on the
 // fragment read (conflict-free ds_read_b128 under the 64-bank / 16-lane-group rule).
 #define PK 32
-template <int WM, int WN, bool CONV, int NS>
-__global__ __launch_bounds__(256) void k_gemm_pipe(GemmArgs a)
+template <int WM, int WN, bool CONV, int NS, int PKT>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
 {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int XI = BM / 64, WI = BN / 64;       // DMA pieces per wave per stage (16 rows x 64 B each)
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int RP = 512 / PKT;                   // rows per 1-KiB DMA piece (16 x 64 B or 8 x 128 B)
+    constexpr int LPR = PKT / 8;                    // lanes (16-B chunks) per row
+    constexpr int XI = BM / (RP * NW), WI = BN / (RP * NW);   // DMA pieces per wave per stage
+    static_assert(XI >= 1 && WI >= 1, "tile too small for the wave count");
     constexpr int G = XI + WI;
-    constexpr int STAGE = (BM + BN) * PK;           // f16 per stage
+    constexpr int STAGE = (BM + BN) * PKT;           // f16 per stage
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -340,15 +352,23 @@ __global__ __launch_bounds__(256) void k_gemm_pipe(GemmArgs a)
     const int bid = xcd_remap(blockIdx.x, a.ntm * a.ntn);
     const int tile_n = bid % a.ntn, tile_m = bid / a.ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int lr = lane >> 2, pc = lane & 3;        // row within the piece's 16 rows, physical 16-B chunk
+    const int lr = lane / LPR, pc = lane % LPR;        // row within the piece's 16 rows, physical 16-B chunk
 
+    const int nk_all = a.K / PKT;
+    const int kbeg = (int)((long)nk_all * blockIdx.y / a.splitk);
+    const int nk = (int)((long)nk_all * (blockIdx.y + 1) / a.splitk) - kbeg;
+
+    // ---- issue-side state: one running source pointer per DMA piece (advanced by a fixed step per stage; rows that
+    // are out of range / conv padding point at a zero page with step 0), so a stage costs G loads + G pointer adds
+    const f16 *xp[XI], *wp[WI];
+    int xst[XI], wst[WI];
     int xoff[XI], xoy[XI], xox[XI], xlc[XI];
     bool xok[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        int row = 16 * (wave + 4 * i) + lr;
+        int row = RP * (wave + NW * i) + lr;
         int m = m0 + row;
-        xlc[i] = (pc ^ ((row >> 2) & 3)) * 8;
+        xlc[i] = (pc ^ (PKT == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7))) * 8;
         xok[i] = m < a.M;
         if (CONV) {
             int hw = a.Ho * a.Wo;
@@ -356,49 +376,54 @@ __global__ __launch_bounds__(256) void k_gemm_pipe(GemmArgs a)
             int oy = p / a.Wo, ox = p - oy * a.Wo;
             xoy[i] = oy * a.stride; xox[i] = ox * a.stride;
             xoff[i] = b * a.H * a.W * a.Cin;
+            xp[i] = g_zero_page; xst[i] = 0;
         } else {
-            xoff[i] = m * a.K; xoy[i] = 0; xox[i] = 0;
+            xoff[i] = 0; xoy[i] = 0; xox[i] = 0;
+            xp[i] = xok[i] ? a.X + (size_t)m * a.K + kbeg * PKT + xlc[i] : g_zero_page;
+            xst[i] = xok[i] ? PKT : 0;
         }
     }
-    int woff[WI], wlc[WI];
-    bool wok[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        int row = 16 * (wave + 4 * i) + lr;
-        wlc[i] = (pc ^ ((row >> 2) & 3)) * 8;
-        wok[i] = (n0 + row) < a.N;
-        woff[i] = (n0 + row) * a.K;
+        int row = RP * (wave + NW * i) + lr;
+        bool ok = (n0 + row) < a.N;
+        wp[i] = ok ? a.Wt + (size_t)(n0 + row) * a.K + kbeg * PKT + ((pc ^ (PKT == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7))) * 8) : g_zero_page;
+        wst[i] = ok ? PKT : 0;
     }
-    const int nk_all = a.K / PK;
-    const int kbeg = (int)((long)nk_all * blockIdx.y / a.splitk);
-    const int nk = (int)((long)nk_all * (blockIdx.y + 1) / a.splitk) - kbeg;
-    auto stage = [&](int kt) {
-        f16 *Xs = smem + (kt % NS) * STAGE;
-        f16 *Ws = Xs + BM * PK;
-        const int k0 = (kbeg + kt) * PK;
+    int k_issue = kbeg * PKT, issued = 0, tap_left = 0;
+
+    auto retap = [&]() {                            // CONV: new 3x3 tap -> recompute the activation pointers
+        int tap = k_issue / a.Cin, c0 = k_issue - tap * a.Cin;
+        int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        int Hv = a.H << a.ups, Wv = a.W << a.ups;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            int iy = xoy[i] + dy, ix = xox[i] + dx;
+            bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+            xp[i] = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 + xlc[i] : g_zero_page;
+            xst[i] = ok ? PKT : 0;
+        }
+        tap_left = (a.Cin - c0) / PKT;
+    };
+    auto issue = [&](int buf) {
         if (CONV) {
-            int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
-            int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            int Hv = a.H << a.ups, Wv = a.W << a.ups;
+            if (tap_left == 0) retap();
+            --tap_left;
+        }
+        f16 *Xs = smem + buf * STAGE;
+        f16 *Ws = Xs + BM * PKT;
 #pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                int iy = xoy[i] + dy, ix = xox[i] + dx;
-                bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-                const f16 *src = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 + xlc[i] : g_zero_page;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (wave + 4 * i) * 512), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const f16 *src = xok[i] ? a.X + xoff[i] + k0 + xlc[i] : g_zero_page;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (wave + 4 * i) * 512), 16, 0, 0);
-            }
+        for (int i = 0; i < XI; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)xp[i], (lptr_t)(Xs + (wave + NW * i) * 512), 16, 0, 0);
+            xp[i] += xst[i];
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            const f16 *src = wok[i] ? a.Wt + woff[i] + k0 + wlc[i] : g_zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ws + (wave + 4 * i) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)wp[i], (lptr_t)(Ws + (wave + NW * i) * 512), 16, 0, 0);
+            wp[i] += wst[i];
         }
+        k_issue += PKT;
+        ++issued;
     };
 
     f32x16 acc[2][2];
@@ -409,33 +434,36 @@ __global__ __launch_bounds__(256) void k_gemm_pipe(GemmArgs a)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    // prologue: NS-1 stages in flight (issue empty groups past the end so the vmcnt arithmetic stays uniform)
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
-        if (p < nk) stage(p);
-    const int swz = (r >> 2) & 3;
-    const int xrow = (wm * 64 + r) * PK, wrow = BM * PK + (wn * 64 + r) * PK;
-    for (int kt = 0; kt < nk; ++kt) {
-        // pieces still allowed in flight after this wait: those of stages kt+1 .. kt+NS-2 that exist
-        int newer = nk - 1 - kt;
-        if (newer > NS - 2) newer = NS - 2;
-        if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) stage(kt + NS - 1);
-        const f16 *sb = smem + (kt % NS) * STAGE;
+        if (p < nk) issue(p);
+    const int swz = PKT == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7);
+    const int xrow = (wm * 64 + r) * PKT, wrow = BM * PKT + (wn * 64 + r) * PKT;
+    for (int kt = 0; kt < nk; kt += NS) {
 #pragma unroll
-        for (int ks = 0; ks < PK / 16; ++ks) {
-            const int pch = ((2 * ks + h) ^ swz) * 8;
-            f16x8 xf0 = *(const f16x8 *)(sb + xrow + pch);
-            f16x8 xf1 = *(const f16x8 *)(sb + xrow + 32 * PK + pch);
-            f16x8 wf0 = *(const f16x8 *)(sb + wrow + pch);
-            f16x8 wf1 = *(const f16x8 *)(sb + wrow + 32 * PK + pch);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf0, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf1, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf1, acc[1][1], 0, 0, 0);
+        for (int u = 0; u < NS; ++u) {
+            if (kt + u < nk) {
+                // pieces still allowed in flight after this wait: those of the (up to NS-2) newer issued stages
+                int newer = issued - 1 - (kt + u);
+                if (NS >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+                else if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (issued < nk) issue((u + NS - 1) % NS);
+                const f16 *sb = smem + u * STAGE;
+#pragma unroll
+                for (int ks = 0; ks < PKT / 16; ++ks) {
+                    const int pch = ((2 * ks + h) ^ swz) * 8;
+                    f16x8 xf0 = *(const f16x8 *)(sb + xrow + pch);
+                    f16x8 xf1 = *(const f16x8 *)(sb + xrow + 32 * PKT + pch);
+                    f16x8 wf0 = *(const f16x8 *)(sb + wrow + pch);
+                    f16x8 wf1 = *(const f16x8 *)(sb + wrow + 32 * PKT + pch);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf0, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf1, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf1, acc[1][1], 0, 0, 0);
+                }
+            }
         }
     }
     if (a.splitk > 1) {
@@ -483,29 +511,46 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a)
     }
 }
 
+static int gemm_impl()
+{
+    static int impl = -1;
+    if (impl < 0) { const char *e = getenv("CTX_GEMM_IMPL"); impl = e ? atoi(e) : 2; }
+    return impl;
+}
+
 template <int WM, int WN, bool CONV>
 static void launch_gemm(GemmArgs &a, hipStream_t s)
 {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     a.ntm = cdiv(a.M, BM);
     a.ntn = cdiv(a.N, BN);
-    static int impl = -1;
-    if (impl < 0) { const char *e = getenv("CTX_GEMM_IMPL"); impl = e ? atoi(e) : 2; }
+    const int impl = gemm_impl();
     if (a.splitk < 1 || !a.part || impl != 2) a.splitk = 1;
     if (impl == 2) {
-        constexpr int NS = 4;
-        size_t lds = (size_t)NS * (BM + BN) * PK * sizeof(f16);
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void *)k_gemm_pipe<WM, WN, CONV, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr2 = true;
+        static int pk64 = -1;
+        if (pk64 < 0) { const char *e = getenv("CTX_GEMM_PK"); pk64 = (e && atoi(e) == 64) ? 1 : 0; }
+        constexpr int NT = 64 * WM * WN;
+        auto go = [&](auto kern, size_t lds, bool &attr_done) {
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_done = true;
+            }
+            if (ctx_prof_on()) {
+                hipEvent_t e0, e1;
+                ctx_prof_events(0, &e0, &e1);
+                hipExtLaunchKernelGGL(kern, dim3(a.ntm * a.ntn, a.splitk), dim3(NT), lds, s, e0, e1, 0, a);
+            } else
+                hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn, a.splitk), dim3(NT), lds, s, a);
+        };
+        if (pk64 && a.K % 64 == 0 && (!CONV || a.Cin % 64 == 0)) {
+            a.pk = 64;
+            static bool d64 = false;
+            go(k_gemm_pipe<WM, WN, CONV, 3, 64>, (size_t)3 * (BM + BN) * 64 * sizeof(f16), d64);
+        } else {
+            a.pk = 32;
+            static bool d32 = false;
+            go(k_gemm_pipe<WM, WN, CONV, 4, 32>, (size_t)4 * (BM + BN) * 32 * sizeof(f16), d32);
         }
-        if (ctx_prof_on()) {
-            hipEvent_t e0, e1;
-            ctx_prof_events(0, &e0, &e1);
-            hipExtLaunchKernelGGL((k_gemm_pipe<WM, WN, CONV, NS>), dim3(a.ntm * a.ntn, a.splitk), dim3(256), lds, s, e0, e1, 0, a);
-        } else
-            hipLaunchKernelGGL((k_gemm_pipe<WM, WN, CONV, NS>), dim3(a.ntm * a.ntn, a.splitk), dim3(256), lds, s, a);
         if (a.splitk > 1) {
             size_t total = (size_t)a.M * (a.N / 4);
             unsigned nb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -550,6 +595,7 @@ int ctx_gemm_pick_split(int M, int N, int K, int epi)
     bool wide = (N % 128 == 0);
     int tiles = wide ? cdiv(M, 128) * cdiv(N, 128) : cdiv(M, 256) * cdiv(N, 64);
     if (tiles >= 200) return 1;
+    if (K < 2048 && tiles > 48) return 1;      // short-K problems: the slab round trip + extra launch costs more than it buys
     int S = 640 / tiles;                       // aim at ~2.5 workgroups per CU
     int maxS = (K / PK) / 8;                   // keep >= 8 stages per split
     if (S > maxS) S = maxS;
@@ -560,12 +606,34 @@ int ctx_gemm_pick_split(int M, int N, int K, int epi)
 // Tile choice: 128x128 when N is a multiple of 128 (no masked columns), else 256x64.
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
 {
-    bool wide = (a.N % 128 == 0) && a.epi == 0;
-    if (a.epi == 1) wide = false;      // GEGLU needs value/gate halves inside one wave tile: both layouts do; keep 256x64
-    if (conv) {
-        if (wide) launch_gemm<2, 2, true>(a, s); else launch_gemm<4, 1, true>(a, s);
+    if (gemm_impl() != 2) {                          // legacy kernels: 4-wave tiles only
+        bool wide = (a.N % 128 == 0) && a.epi == 0;
+        if (conv) { if (wide) launch_gemm<2, 2, true>(a, s); else launch_gemm<4, 1, true>(a, s); }
+        else { if (wide) launch_gemm<2, 2, false>(a, s); else launch_gemm<4, 1, false>(a, s); }
     } else {
-        if (wide) launch_gemm<2, 2, false>(a, s); else launch_gemm<4, 1, false>(a, s);
+        // Tile choice: the largest tile (most flops per LDS-fill byte) that still gives the chip >= ~1.5 workgroups
+        // per CU once split-K is counted; small problems fall through to 128x64 (2 waves) / 64x64 (1 wave) tiles.
+        static int big = -1;
+        if (big < 0) { const char *e = getenv("CTX_GEMM_BIG"); big = e ? atoi(e) : 1; }
+        const int S = a.splitk > 1 && a.part ? a.splitk : 1;
+        auto wgs = [&](int bm, int bn) { return cdiv(a.M, bm) * cdiv(a.N, bn) * S; };
+        const bool n128 = (a.N % 128 == 0);
+        int pick;
+        if (big && a.M >= 8192 && a.N >= 256 && a.K >= 1024) pick = 0;                 // 256x128, 8 waves
+        else if (n128 && wgs(128, 128) >= 384) pick = 1;                               // 128x128
+        else if (!n128 && wgs(256, 64) >= 384) pick = 2;                               // 256x64
+        else if (wgs(128, 64) >= 320) pick = 3;                                        // 128x64, 2 waves
+        else if (S > 1) pick = n128 ? 1 : 2;                                           // split-K already spreads it
+        else pick = 4;                                                                 // 64x64, 1 wave
+#define CTX_LAUNCH(WM_, WN_) do { if (conv) launch_gemm<WM_, WN_, true>(a, s); else launch_gemm<WM_, WN_, false>(a, s); } while (0)
+        switch (pick) {
+        case 0: CTX_LAUNCH(4, 2); break;
+        case 1: CTX_LAUNCH(2, 2); break;
+        case 2: CTX_LAUNCH(4, 1); break;
+        case 3: CTX_LAUNCH(2, 1); break;
+        default: CTX_LAUNCH(1, 1); break;
+        }
+#undef CTX_LAUNCH
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

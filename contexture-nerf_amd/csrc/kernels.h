@@ -19,6 +19,7 @@ struct GemmArgs {
     int ntm, ntn;
     int splitk;            // >1: grid.y = splitk, fp32 partials [splitk][M][N] go to `part`
     float *part;
+    int pk;                // K-stage depth chosen by the launcher (32 or 64)
 };
 
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s);

@@ -53,66 +53,104 @@ __global__ void k_gn_stats(const f16 *__restrict__ x, int HW, int C, int G, int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, const f16 *__restrict__ gamma,
-                                                  const f16 *__restrict__ beta, int HW, int C, int G, int NS, float eps,
-                                                  int silu, const float *__restrict__ part, f16 *__restrict__ y)
+// finalize: per (batch, channel) affine  y = x*sa + sb  from the split partials (fixed summation order)
+__global__ __launch_bounds__(256) void k_gn_finalize(const float *__restrict__ part, const f16 *__restrict__ gamma,
+                                                     const f16 *__restrict__ beta, int HW, int C, int G, int NS, float eps,
+                                                     float *__restrict__ ab)
 {
     __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
-    const int b = blockIdx.y;
-    if (threadIdx.x < G) {
-        float s = 0.f, q = 0.f;
-        for (int k = 0; k < NS; ++k) {
-            s += part[(((size_t)b * NS + k) * G + threadIdx.x) * 2 + 0];
-            q += part[(((size_t)b * NS + k) * G + threadIdx.x) * 2 + 1];
+    const int b = blockIdx.x;
+    // 256/G lanes per group sum interleaved partials, then a fixed-order shuffle tree (deterministic)
+    const int lpg = 256 / G;                      // G in {32, 64} -> 8 or 4 lanes
+    const int g = threadIdx.x / lpg, l = threadIdx.x % lpg;
+    float s = 0.f, q = 0.f;
+    if (g < G)
+        for (int k = l; k < NS; k += lpg) {
+            s += part[(((size_t)b * NS + k) * G + g) * 2 + 0];
+            q += part[(((size_t)b * NS + k) * G + g) * 2 + 1];
         }
+    for (int o = lpg >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (g < G && l == 0) {
         float n = (float)HW * (float)(C / G);
         float mean = s / n;
         float var = fmaxf(q / n - mean * mean, 0.f);
-        s_mean[threadIdx.x] = mean;
-        s_rstd[threadIdx.x] = rsqrtf(var + eps);
+        s_mean[g] = mean;
+        s_rstd[g] = rsqrtf(var + eps);
     }
     __syncthreads();
-    const int c8n = C / 8, cg = C / G;
-    const size_t total = (size_t)HW * c8n;
-    const f16 *xb = x + (size_t)b * HW * C;
-    f16 *yb = y + (size_t)b * HW * C;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        int c8 = (int)(i % c8n);
-        f16x8 v = *(const f16x8 *)(xb + i * 8);
-        f16x8 ga = *(const f16x8 *)(gamma + c8 * 8);
-        f16x8 be = *(const f16x8 *)(beta + c8 * 8);
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int g = (c8 * 8 + j) / cg;
-            float f = ((float)v[j] - s_mean[g]) * s_rstd[g] * (float)ga[j] + (float)be[j];
-            if (silu) f = f / (1.0f + __expf(-f));
-            o[j] = (f16)f;
-        }
-        *(f16x8 *)(yb + i * 8) = o;
+    const int cg = C / G;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        int gg = c / cg;
+        float sa = s_rstd[gg] * (float)gamma[c];
+        ab[((size_t)b * 2 + 0) * C + c] = sa;
+        ab[((size_t)b * 2 + 1) * C + c] = (float)beta[c] - s_mean[gg] * sa;
     }
 }
 
-extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups) { return (int64_t)B * 64 * groups * 2 * 4; }
+__global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, const float *__restrict__ ab, int HW, int C,
+                                                  int silu, f16 *__restrict__ y)
+{
+    extern __shared__ float s_ab[];          // [2][C]
+    const int b = blockIdx.y;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) s_ab[c] = ab[(size_t)b * 2 * C + c];
+    __syncthreads();
+    const int c8n = C / 8;
+    const f16 *xb = x + (size_t)b * HW * C;
+    f16 *yb = y + (size_t)b * HW * C;
+    const unsigned total = (unsigned)HW * (unsigned)c8n;
+    const unsigned stride = gridDim.x * 256u;
+    unsigned i = blockIdx.x * 256u + threadIdx.x;
+    unsigned c8 = i % (unsigned)c8n;
+    const unsigned cstep = stride % (unsigned)c8n;
+    for (; i < total; i += stride) {
+        int c0 = (int)c8 * 8;
+        f16x8 v = *(const f16x8 *)(xb + (size_t)i * 8);
+        f32x4 a0 = *(const f32x4 *)(s_ab + c0), a1 = *(const f32x4 *)(s_ab + c0 + 4);
+        f32x4 b0 = *(const f32x4 *)(s_ab + C + c0), b1 = *(const f32x4 *)(s_ab + C + c0 + 4);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = (float)v[j] * a0[j] + b0[j]; f[4 + j] = (float)v[4 + j] * a1[j] + b1[j]; }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = f[j];
+            if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+            o[j] = (f16)t;
+        }
+        *(f16x8 *)(yb + (size_t)i * 8) = o;
+        c8 += cstep;
+        if (c8 >= (unsigned)c8n) c8 -= (unsigned)c8n;
+    }
+}
+
+#define GN_MAX_SPLITS 256
+#define GN_MAX_C 4096
+extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups)
+{
+    return ((int64_t)B * GN_MAX_SPLITS * groups * 2 + (int64_t)B * 2 * GN_MAX_C) * 4;
+}
 
 extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const void *beta, int32_t B, int32_t HW, int32_t C,
                                      int32_t groups, float eps, int32_t silu, void *y, void *stats_ws, ctx_stream_t stream)
 {
     CTX_REQUIRE(x && gamma && beta && y && stats_ws, "groupnorm: null pointer");
-    CTX_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS && C / 8 <= 1024,
+    CTX_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS && C <= GN_MAX_C &&
+                    256 % groups == 0 && (256 / groups & (256 / groups - 1)) == 0,
                 "groupnorm: unsupported B=%d HW=%d C=%d groups=%d", B, HW, C, groups);
     hipStream_t s = (hipStream_t)stream;
     int c8n = C / 8;
     int PL = c8n >= 256 ? 1024 / c8n : 256 / c8n;
     if (PL < 1) PL = 1;
     int threads = c8n * PL;
-    int NS = min(64, max(1, HW / (PL * 4)));
+    int NS = min(GN_MAX_SPLITS, max(1, HW / (PL * 8)));
+    float *part = (float *)stats_ws;
+    float *ab = part + (size_t)B * GN_MAX_SPLITS * groups * 2;
     size_t lds = (size_t)PL * C * 2 * sizeof(float);          // <= 64 KiB (threads <= 1024, 8 channels each)
-    hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), lds, s, (const f16 *)x, HW, C, groups, NS, (float *)stats_ws);
+    hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), lds, s, (const f16 *)x, HW, C, groups, NS, part);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(256), 0, s, part, (const f16 *)gamma, (const f16 *)beta, HW, C, groups, NS, eps, ab);
     size_t total = (size_t)HW * c8n;
-    int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), 0, s, (const f16 *)x, (const f16 *)gamma, (const f16 *)beta, HW, C,
-                       groups, NS, eps, silu, (const float *)stats_ws, (f16 *)y);
+    int nb = (int)((total + 1023) / 1024 < 1024 ? (total + 1023) / 1024 : 1024);
+    hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, (const f16 *)x, ab, HW, C, silu, (f16 *)y);
     CTX_CHECK_LAUNCH("groupnorm");
     return CTX_OK;
 }

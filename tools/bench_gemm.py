@@ -10,6 +10,7 @@ from contexture_nerf_amd import _lib as L
 lib = L.load()
 dev = torch.device('cuda:0')
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+only = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else None
 # (kind, M or (B,H,W), N/Cout, K/Cin)
 shapes = [("conv", (2, 96, 96), 320, 320), ("conv", (2, 48, 48), 640, 640), ("conv", (2, 24, 24), 1280, 1280),
           ("conv", (2, 12, 12), 1280, 1280), ("conv", (2, 96, 96), 320, 640), ("conv", (2, 48, 48), 640, 1280),
@@ -17,6 +18,8 @@ shapes = [("conv", (2, 96, 96), 320, 320), ("conv", (2, 48, 48), 640, 640), ("co
           ("gemm", 18432, 320, 320), ("gemm", 18432, 960, 320), ("gemm", 18432, 2560, 320), ("gemm", 18432, 320, 1280),
           ("gemm", 4608, 640, 640), ("gemm", 4608, 5120, 640), ("gemm", 4608, 640, 2560),
           ("gemm", 1152, 1280, 1280), ("gemm", 1152, 10240, 1280), ("gemm", 1152, 1280, 5120), ("gemm", 154, 640, 1024)]
+if only is not None:
+    shapes = [shapes[i] for i in only]
 g = torch.Generator(device=dev).manual_seed(0)
 items = []
 for s in shapes:
