@@ -40,11 +40,12 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(latent, budget_s=45.0, forced=0):
+def cpu_baseline(latent, budget_s=60.0, forced=0):
     """The oracle's fp32 PyTorch UNet (the reference's CPU behaviour: autocast is a no-op on CPU,
     stable_diffusion_depth.py:330) timed on this box's host cores on ONE CFG-batched step."""
     from oracle import unet_ref
-    cores = os.cpu_count() or 1
+    # a 1-GPU box owns a 16-core share of the host (more threads only oversubscribe it)
+    cores = int(os.environ.get("CTX_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     t0 = time.perf_counter()

@@ -3,7 +3,10 @@ the same ops, and of the whole engine against the oracle's fp32 UNet (oracle/une
 
 Tolerances (stated per test): operands/outputs are fp16 with fp32 accumulation, so a single op is
 compared to the fp32 result of the SAME fp16-rounded inputs within 2^-10 relative (+ small abs);
-the end-to-end denoised output is held to <= 1e-3 relative L2 (north_star: "within 1e-3 rel fp16")."""
+the end-to-end output is held (a) against pure fp32 to within 1.25x of what fp16 storage itself costs — measured by
+the oracle's fp16-storage restatement of the reference's autocast contract — and (b) to <= 1.6e-3 relative L2 against
+that restatement.  north_star's "within 1e-3 rel fp16" is below the noise floor of fp16-operand arithmetic on this
+network: fp16 WEIGHTS alone put any fp16 implementation 0.84e-3 from fp32 (tests/test_precision_cpu.py)."""
 import ctypes as C
 import numpy as np
 import pytest
@@ -189,12 +192,20 @@ def test_unet_vs_oracle(dev, cfgname, h, w, L):
     ctx = torch.randn(2, L, cfg['cross_attention_dim'], generator=g)
     for t in (981.0, 1.0):
         with torch.no_grad():
-            want = ref(x, torch.tensor(t), ctx)['sample']
+            want32 = ref(x, torch.tensor(t), ctx)['sample']
+        want16 = unet_ref.forward_fp16_storage(ref, x, torch.tensor(t), ctx)['sample']     # the reference's autocast contract
         got = net(x.to(dev), t, ctx.to(dev))['sample']
-        assert got.shape == want.shape and torch.isfinite(got).all()
-        r = _rel(got, want)
-        assert r < 1e-3 * 3, f"UNet {cfgname} t={t}: rel L2 {r:.3e}"      # see DESIGN.md: 1e-3 target, 3e-3 gate on random-init
-        print(f"unet {cfgname} {h}x{w} t={t}: rel L2 = {r:.3e}")
+        assert got.shape == want32.shape and torch.isfinite(got).all()
+        r16, r32, floor = _rel(got, want16), _rel(got, want32), _rel(want16, want32)
+        print(f"unet {cfgname} {h}x{w} t={t}: rel L2 vs fp16-storage restatement {r16:.3e} | vs fp32 {r32:.3e} | "
+              f"restatement vs fp32 {floor:.3e}")
+        # Two fp16-storage evaluations that differ only in fp32 accumulation order decorrelate at every rounding point, so
+        # they sit ~sqrt(2) x the activation-rounding noise apart (measured 1.26-1.34e-3 here; the restatement itself is
+        # 1.3-1.5e-3 from fp32 and fp16 WEIGHTS alone cost 0.84e-3: tests/test_precision_cpu.py).  north_star's "1e-3 rel"
+        # is therefore below the noise floor of fp16-operand arithmetic on this network; the gates are the floor-relative
+        # ones below ("UNet tolerance").
+        assert r16 < 1.6e-3, f"UNet {cfgname} t={t}: {r16:.3e} vs the fp16-storage restatement"
+        assert r32 < 1.25 * floor + 2e-4, f"UNet {cfgname} t={t}: {r32:.3e} vs fp32 exceeds the fp16-storage floor {floor:.3e}"
 
 
 def test_unet_sd2_depth_shapes_and_determinism(dev):
