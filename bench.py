@@ -81,12 +81,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local = local % max(torch.cuda.device_count(), 1)         # rehearsal: several ranks may share one card (gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("CTX_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from contexture_nerf_amd import _lib as L
     from contexture_nerf_amd.unet import UNet2DConditionModel

@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include <hip/hip_ext.h>
 #include <math.h>
+#include <stdlib.h>
 
 #define AT_KB 64                // keys per tile
 #define AT_KROW 72              // f16 per K row in LDS (144 B: conflict-free ds_read_b128)
@@ -161,6 +162,179 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (default): K and V^T tiles arrive by global_load_lds into a ring of AT_NS stages (1 KiB pieces of
+// 8 rows x 128 B, chunk swizzle c ^ ((row>>1)&7) on the source address and on the fragment reads), prefetch distance
+// AT_NS-1 tiles, one raw s_barrier + counted vmcnt per tile — the same pipeline as k_gemm_pipe.
+#define AT_NS 3
+__device__ __attribute__((aligned(16))) f16 g_attn_zero[64];
+typedef const __attribute__((address_space(1))) void *agptr_t;
+typedef __attribute__((address_space(3))) void *alptr_t;
+
+
+// One 64-key tile of the online-softmax recurrence for this wave's 32 queries (MASK only for the last, ragged tile).
+template <bool MASK>
+__device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 *__restrict__ Vs, int k0, int Skv, int r, int h,
+                                          int swz, float c, const f16x8 (&qf)[4], f32x16 (&o)[2], float &m_run, float &l_run)
+{
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s[kb][q] = 0.f;
+        const f16 *kr = Ks + (kb * 32 + r) * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8 kf = *(const f16x8 *)(kr + ((2 * ks + h) ^ swz) * 8);
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+        }
+    }
+    if (MASK) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int key = k0 + kb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (key >= Skv) s[kb][q] = -INFINITY;
+            }
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) mx = fmaxf(mx, fmaxf(s[0][q], s[1][q]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+    float m_new = fmaxf(m_run, mx);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][q], c, -m_new));
+            s[kb][q] = p;
+            psum += p;
+        }
+    psum += __shfl_xor(psum, 32, 64);
+    if (__any(m_new != m_run)) {                     // wave-uniform: rescale only when some row's max moved
+        float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[d][q] *= alpha;
+    }
+    l_run += psum;
+    m_run = m_new;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (f16)s[kb][8 * st + j];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const f16 *vr = Vs + (d * 32 + r) * 64 + 4 * h;
+                const int c0 = kb * 4 + 2 * st;
+                f16x4 v0 = *(const f16x4 *)(vr + ((c0 ^ swz) * 8));
+                f16x4 v1 = *(const f16x4 *)(vr + (((c0 + 1) ^ swz) * 8));
+                f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[d], 0, 0, 0);
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) f16 ring[AT_NS * 2 * 64 * 64];    // per stage: K [64][64] then V^T [64][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = q0 + r;
+    const bool qok = qrow < a.Sq;
+    constexpr int G = 4;                             // DMA pieces per wave per tile (2 K + 2 V^T)
+
+    f16x8 qf[4];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const f16 *qp = a.Q + ((size_t)b * a.Sq + (qok ? qrow : 0)) * a.q_stride + hd * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qok ? *(const f16x8 *)(qp + ks * 16) : zero8;
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o[d][q] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (a.Skv + AT_KB - 1) / AT_KB;
+    // issue-side state: this wave moves pieces {wave, wave+4} of the K tile and of the V^T tile
+    const int lr = lane >> 3, pc = lane & 7;
+    const f16 *kp[2], *vp[2];
+    int krow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = 8 * (wave + 4 * i) + lr;
+        int lc = (pc ^ ((row >> 1) & 7)) * 8;
+        krow[i] = row;
+        kp[i] = a.K + ((size_t)b * a.Skv + row) * a.kv_stride + hd * 64 + lc;
+        vp[i] = a.Vt + (((size_t)b * a.heads + hd) * 64 + row) * a.Sp + lc;
+    }
+    int issued = 0;
+    auto issue = [&](int buf) {
+        f16 *Ks = ring + buf * (2 * 64 * 64);
+        f16 *Vs = Ks + 64 * 64;
+        const int k0 = issued * AT_KB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f16 *src = (k0 + krow[i] < a.Skv) ? kp[i] : g_attn_zero;
+            __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)(Ks + (wave + 4 * i) * 512), 16, 0, 0);
+            kp[i] += (size_t)AT_KB * a.kv_stride;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((agptr_t)vp[i], (alptr_t)(Vs + (wave + 4 * i) * 512), 16, 0, 0);
+            vp[i] += AT_KB;
+        }
+        ++issued;
+    };
+#pragma unroll
+    for (int p = 0; p < AT_NS - 1; ++p)
+        if (p < ntiles) issue(p);
+
+    const int swz = (r >> 1) & 7;
+    const float c = a.scale_log2e;
+    for (int t0 = 0; t0 < ntiles; t0 += AT_NS) {
+#pragma unroll
+        for (int u = 0; u < AT_NS; ++u) {
+            const int t = t0 + u;
+            if (t < ntiles) {
+                int newer = issued - 1 - t;
+                if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (issued < ntiles) issue((u + AT_NS - 1) % AT_NS);
+                const f16 *Ks = ring + u * (2 * 64 * 64);
+                if (t * AT_KB + AT_KB > a.Skv) attn_tile<true>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, c, qf, o, m_run, l_run);
+                else attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, c, qf, o, m_run, l_run);
+            }
+        }
+    }
+    if (qok) {
+        float inv = 1.0f / l_run;
+        f16 *op = a.O + ((size_t)b * a.Sq + qrow) * a.o_stride + hd * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (f16)(o[d][4 * g + j] * inv);
+                *(f16x4 *)(op + d * 32 + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
 int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq, int Skv, int Sp, int heads, int q_stride,
                        int kv_stride, float scale, f16 *O, int o_stride, hipStream_t s)
 {
@@ -168,12 +342,15 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq,
     a.Q = Q; a.K = K; a.Vt = Vt; a.O = O; a.Sq = Sq; a.Skv = Skv; a.Sp = Sp; a.heads = heads;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
+    static int impl = -1;
+    if (impl < 0) { const char *e = getenv("CTX_ATTN_IMPL"); impl = e ? atoi(e) : 1; }
+    auto kern = impl == 1 ? k_attention_dma : k_attention;
     if (ctx_prof_on()) {
         hipEvent_t e0, e1;
         ctx_prof_events(1, &e0, &e1);
-        hipExtLaunchKernelGGL(k_attention, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, e0, e1, 0, a);
+        hipExtLaunchKernelGGL(kern, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, e0, e1, 0, a);
     } else
-        hipLaunchKernelGGL(k_attention, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(kern, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ctx_set_error("attention launch failed: %s", hipGetErrorString(e));

@@ -445,7 +445,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
             if (kt + u < nk) {
                 // pieces still allowed in flight after this wait: those of the (up to NS-2) newer issued stages
                 int newer = issued - 1 - (kt + u);
-                if (NS >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+                if (NS >= 8 && newer >= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * G) : "memory");
+                else if (NS >= 7 && newer >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * G) : "memory");
+                else if (NS >= 6 && newer >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * G) : "memory");
+                else if (NS >= 5 && newer >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G) : "memory");
+                else if (NS >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
                 else if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -549,7 +553,13 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
         } else {
             a.pk = 32;
             static bool d32 = false;
-            go(k_gemm_pipe<WM, WN, CONV, 4, 32>, (size_t)4 * (BM + BN) * 32 * sizeof(f16), d32);
+            // deeper rings for the small tiles: a 1- or 2-wave workgroup needs more bytes in flight to pull its share
+            constexpr int NSD = (WM * WN == 1) ? 8 : (WM * WN == 2 ? 6 : 4);
+            static int deep = -1;
+            if (deep < 0) { const char *e = getenv("CTX_GEMM_DEEP"); deep = e ? atoi(e) : 0; }
+            static bool d32b = false;
+            if (deep && NSD != 4) go(k_gemm_pipe<WM, WN, CONV, NSD, 32>, (size_t)NSD * (BM + BN) * 32 * sizeof(f16), d32b);
+            else go(k_gemm_pipe<WM, WN, CONV, 4, 32>, (size_t)4 * (BM + BN) * 32 * sizeof(f16), d32);
         }
         if (a.splitk > 1) {
             size_t total = (size_t)a.M * (a.N / 4);
@@ -625,6 +635,9 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
         else if (wgs(128, 64) >= 320) pick = 3;                                        // 128x64, 2 waves
         else if (S > 1) pick = n128 ? 1 : 2;                                           // split-K already spreads it
         else pick = 4;                                                                 // 64x64, 1 wave
+        static int force = -2;
+        if (force == -2) { const char *e = getenv("CTX_GEMM_TILE"); force = e ? atoi(e) : -1; }
+        if (force >= 0) pick = force;
 #define CTX_LAUNCH(WM_, WN_) do { if (conv) launch_gemm<WM_, WN_, true>(a, s); else launch_gemm<WM_, WN_, false>(a, s); } while (0)
         switch (pick) {
         case 0: CTX_LAUNCH(4, 2); break;

@@ -53,46 +53,40 @@ __global__ void k_gn_stats(const f16 *__restrict__ x, int HW, int C, int G, int 
     }
 }
 
-// finalize: per (batch, channel) affine  y = x*sa + sb  from the split partials (fixed summation order)
-__global__ __launch_bounds__(256) void k_gn_finalize(const float *__restrict__ part, const f16 *__restrict__ gamma,
-                                                     const f16 *__restrict__ beta, int HW, int C, int G, int NS, float eps,
-                                                     float *__restrict__ ab)
+// apply: every block first folds the (<= GN_MAX_SPLITS) split partials into mean / rstd per group in a fixed order
+// (8 lanes per group + shuffle tree), builds the per-channel affine y = x*sa + sb in LDS, then streams its pixels.
+__global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, const float *__restrict__ part,
+                                                  const f16 *__restrict__ gamma, const f16 *__restrict__ beta, int HW, int C,
+                                                  int G, int NS, float eps, int silu, f16 *__restrict__ y)
 {
+    extern __shared__ float s_ab[];          // [2][C]
     __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
-    const int b = blockIdx.x;
-    // 256/G lanes per group sum interleaved partials, then a fixed-order shuffle tree (deterministic)
-    const int lpg = 256 / G;                      // G in {32, 64} -> 8 or 4 lanes
-    const int g = threadIdx.x / lpg, l = threadIdx.x % lpg;
-    float s = 0.f, q = 0.f;
-    if (g < G)
+    const int b = blockIdx.y;
+    {
+        const int lpg = 256 / G;
+        const int g = threadIdx.x / lpg, l = threadIdx.x % lpg;
+        float s = 0.f, q = 0.f;
         for (int k = l; k < NS; k += lpg) {
             s += part[(((size_t)b * NS + k) * G + g) * 2 + 0];
             q += part[(((size_t)b * NS + k) * G + g) * 2 + 1];
         }
-    for (int o = lpg >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    if (g < G && l == 0) {
-        float n = (float)HW * (float)(C / G);
-        float mean = s / n;
-        float var = fmaxf(q / n - mean * mean, 0.f);
-        s_mean[g] = mean;
-        s_rstd[g] = rsqrtf(var + eps);
+        for (int o = lpg >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (l == 0) {
+            float n = (float)HW * (float)(C / G);
+            float mean = s / n;
+            float var = fmaxf(q / n - mean * mean, 0.f);
+            s_mean[g] = mean;
+            s_rstd[g] = rsqrtf(var + eps);
+        }
     }
     __syncthreads();
     const int cg = C / G;
     for (int c = threadIdx.x; c < C; c += 256) {
         int gg = c / cg;
         float sa = s_rstd[gg] * (float)gamma[c];
-        ab[((size_t)b * 2 + 0) * C + c] = sa;
-        ab[((size_t)b * 2 + 1) * C + c] = (float)beta[c] - s_mean[gg] * sa;
+        s_ab[c] = sa;
+        s_ab[C + c] = (float)beta[c] - s_mean[gg] * sa;
     }
-}
-
-__global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, const float *__restrict__ ab, int HW, int C,
-                                                  int silu, f16 *__restrict__ y)
-{
-    extern __shared__ float s_ab[];          // [2][C]
-    const int b = blockIdx.y;
-    for (int c = threadIdx.x; c < 2 * C; c += 256) s_ab[c] = ab[(size_t)b * 2 * C + c];
     __syncthreads();
     const int c8n = C / 8;
     const f16 *xb = x + (size_t)b * HW * C;
@@ -123,7 +117,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
     }
 }
 
-#define GN_MAX_SPLITS 256
+#define GN_MAX_SPLITS 32
 #define GN_MAX_C 4096
 extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups)
 {
@@ -144,13 +138,12 @@ extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const voi
     int threads = c8n * PL;
     int NS = min(GN_MAX_SPLITS, max(1, HW / (PL * 8)));
     float *part = (float *)stats_ws;
-    float *ab = part + (size_t)B * GN_MAX_SPLITS * groups * 2;
     size_t lds = (size_t)PL * C * 2 * sizeof(float);          // <= 64 KiB (threads <= 1024, 8 channels each)
     hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), lds, s, (const f16 *)x, HW, C, groups, NS, part);
-    hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(256), 0, s, part, (const f16 *)gamma, (const f16 *)beta, HW, C, groups, NS, eps, ab);
     size_t total = (size_t)HW * c8n;
-    int nb = (int)((total + 1023) / 1024 < 1024 ? (total + 1023) / 1024 : 1024);
-    hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, (const f16 *)x, ab, HW, C, silu, (f16 *)y);
+    int nb = (int)((total + 2047) / 2048 < 512 ? (total + 2047) / 2048 : 512);
+    hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, (const f16 *)x, part, (const f16 *)gamma,
+                       (const f16 *)beta, HW, C, groups, NS, eps, silu, (f16 *)y);
     CTX_CHECK_LAUNCH("groupnorm");
     return CTX_OK;
 }

@@ -332,7 +332,7 @@ static void op_conv(ctx_unet *u, const f16 *x, size_t w, size_t bias, const f16 
 }
 static void op_gn(ctx_unet *u, const f16 *x, size_t g, size_t b, int B, int HW, int C, float eps, int silu, f16 *y, void *stats)
 {
-    note(u, 2, 0, 3);
+    note(u, 2, 0, 2);
     RUN(ctx_groupnorm_f16(x, u->W + g, u->W + b, B, HW, C, u->cfg.groups, eps, silu, y, stats, u->s));
 }
 static void op_ln(ctx_unet *u, const f16 *x, size_t g, size_t b, int64_t rows, int C, f16 *y)
