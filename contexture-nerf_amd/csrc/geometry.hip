@@ -96,13 +96,14 @@ extern "C" int32_t ctx_prepare_vertices(const float *verts, const int64_t *faces
 #define FT_W 32
 #define FT_H 8
 
-struct FaceRec {   // 64 B
+struct __attribute__((aligned(16))) FaceRec {   // 64 B, bbox first so it is one aligned 16-byte load
+    float xmin, xmax, ymin, ymax;
     float ax, ay, bx, by, cx, cy;
     float z0, z1, z2;
-    float xmin, xmax, ymin, ymax;
     int id;
     int pad0, pad1;
 };
+static_assert(sizeof(FaceRec) == 64, "FaceRec must be 64 bytes");
 
 __device__ __forceinline__ void load_face(const float *__restrict__ fxy, const float *__restrict__ fz,
                                           int zstride, float mult, FaceRec &r)
@@ -123,8 +124,21 @@ __device__ __forceinline__ bool rect_overlap(const FaceRec &r, float xlo, float 
     return !(xhi < r.xmin || xlo >= r.xmax || yhi < r.ymin || ylo >= r.ymax);
 }
 
-__global__ __launch_bounds__(256) void k_raster_bin(int H, int W, const float *__restrict__ fz, int zstride,
-                                                    const float *__restrict__ fxy, int F, float mult,
+// per-(view, face) record: scaled vertices, z, bbox — computed once, read as four 16-byte vectors afterwards
+__global__ __launch_bounds__(256) void k_raster_setup(const float *__restrict__ fz, int zstride, const float *__restrict__ fxy,
+                                                      int F, float mult, FaceRec *__restrict__ recs, float4 *__restrict__ bbox)
+{
+    int b = blockIdx.y;
+    int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    FaceRec r;
+    load_face(fxy + ((size_t)b * F + f) * 6, fz + ((size_t)b * F + f) * 3 * zstride, zstride, mult, r);
+    r.id = f; r.pad0 = 0; r.pad1 = 0;
+    recs[(size_t)b * F + f] = r;
+    bbox[(size_t)b * F + f] = make_float4(r.xmin, r.xmax, r.ymin, r.ymax);   // compact copy: 16 B per face for the culls
+}
+
+__global__ __launch_bounds__(256) void k_raster_bin(int H, int W, const float4 *__restrict__ bbox, int F, float mult,
                                                     int ntx, int nty, int *__restrict__ lists,
                                                     int *__restrict__ counts)
 {
@@ -139,15 +153,13 @@ __global__ __launch_bounds__(256) void k_raster_bin(int H, int W, const float *_
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
     int *list = lists + ((size_t)b * ntx * nty + tile) * F;
-    const float *xyb = fxy + (size_t)b * F * 6;
-    const float *zb = fz + (size_t)b * F * 3 * zstride;
+    const float4 *bbv = bbox + (size_t)b * F;
     for (int f0 = 0; f0 < F; f0 += 256) {
         int f = f0 + threadIdx.x;
         bool keep = false;
         if (f < F) {
-            FaceRec r;
-            load_face(xyb + (size_t)f * 6, zb + (size_t)f * 3 * zstride, zstride, mult, r);
-            keep = rect_overlap(r, xlo, xhi, ylo, yhi);
+            const float4 bb = bbv[f];                             // xmin, xmax, ymin, ymax
+            keep = !(xhi < bb.x || xlo >= bb.y || yhi < bb.z || ylo >= bb.w);
         }
         unsigned long long m = __ballot(keep);
         int lane = threadIdx.x & 63;
@@ -162,14 +174,15 @@ __global__ __launch_bounds__(256) void k_raster_bin(int H, int W, const float *_
 
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_raster(int H, int W, const float *__restrict__ fz, int zstride,
-                                                const float *__restrict__ fxy, const float *__restrict__ feat,
+                                                const FaceRec *__restrict__ recs, const float4 *__restrict__ bbox,
+                                                const float *__restrict__ feat,
                                                 int featB, int C, const float *__restrict__ fnorm, int F,
                                                 float mult, float eps, int ntx, int nty,
                                                 const int *__restrict__ lists, const int *__restrict__ counts,
                                                 float *__restrict__ out, float *__restrict__ out_uv,
                                                 int64_t *__restrict__ face_idx, float *__restrict__ normals)
 {
-    __shared__ FaceRec s_rec[256];
+    __shared__ __attribute__((aligned(16))) FaceRec s_rec[256];
     __shared__ int s_n;
     int b = blockIdx.z;
     int fi0 = blockIdx.x * FT_W, fj0 = blockIdx.y * FT_H;
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(256) void k_raster(int H, int W, const float *__res
     int ctile = (fj0 / COARSE) * ntx + (fi0 / COARSE);
     const int *list = lists + ((size_t)b * ntx * nty + ctile) * F;
     int n = counts[(size_t)b * ntx * nty + ctile];
-    const float *xyb = fxy + (size_t)b * F * 6;
+    const FaceRec *rb = recs + (size_t)b * F;
     const float *zb = fz + (size_t)b * F * 3 * zstride;
 
     float best = -INFINITY, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
@@ -195,12 +208,12 @@ __global__ __launch_bounds__(256) void k_raster(int H, int W, const float *__res
         int k = c0 + threadIdx.x;
         if (k < n) {
             int f = list[k];
-            FaceRec r;
-            load_face(xyb + (size_t)f * 6, zb + (size_t)f * 3 * zstride, zstride, mult, r);
-            if (rect_overlap(r, txlo, txhi, tylo, tyhi)) {
-                r.id = f;
+            const float4 bb = bbox[(size_t)b * F + f];
+            if (!(txhi < bb.x || txlo >= bb.y || tyhi < bb.z || tylo >= bb.w)) {
                 int slot = atomicAdd(&s_n, 1);
-                s_rec[slot] = r;
+                const float4 *src = (const float4 *)&rb[f];
+                float4 *dst = (float4 *)&s_rec[slot];
+                dst[0] = bb; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
             }
         }
         __syncthreads();
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(256) void k_raster(int H, int W, const float *__res
 extern "C" int64_t ctx_rasterize_ws_bytes(int32_t H, int32_t W, int32_t B, int32_t F)
 {
     int64_t nt = (int64_t)cdiv(W, COARSE) * cdiv(H, COARSE);
-    return ((int64_t)B * nt * F + (int64_t)B * nt) * 4 + 256;
+    return ((int64_t)B * nt * F + (int64_t)B * nt) * 4 + (int64_t)B * F * (64 + 16) + 512;
 }
 
 static int32_t raster_common(bool fused, int H, int W, const float *fz, int zstride, const float *fxy,
@@ -274,15 +287,18 @@ static int32_t raster_common(bool fused, int H, int W, const float *fz, int zstr
     CTX_REQUIRE(ws_bytes >= ctx_rasterize_ws_bytes(H, W, B, F), "rasterize: workspace too small (%lld < %lld)",
                 (long long)ws_bytes, (long long)ctx_rasterize_ws_bytes(H, W, B, F));
     int ntx = cdiv(W, COARSE), nty = cdiv(H, COARSE);
-    int *lists = (int *)ws;
+    FaceRec *recs = (FaceRec *)(((uintptr_t)ws + 63) & ~(uintptr_t)63);
+    float4 *bbox = (float4 *)(recs + (size_t)B * F);
+    int *lists = (int *)(bbox + (size_t)B * F);
     int *counts = lists + (size_t)B * ntx * nty * F;
-    hipLaunchKernelGGL(k_raster_bin, dim3(ntx * nty, B), dim3(256), 0, s, H, W, fz, zstride, fxy, F, mult, ntx, nty, lists, counts);
+    hipLaunchKernelGGL(k_raster_setup, dim3(cdiv(F, 256), B), dim3(256), 0, s, fz, zstride, fxy, F, mult, recs, bbox);
+    hipLaunchKernelGGL(k_raster_bin, dim3(ntx * nty, B), dim3(256), 0, s, H, W, bbox, F, mult, ntx, nty, lists, counts);
     dim3 grid(cdiv(W, FT_W), cdiv(H, FT_H), B);
     if (fused)
-        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, H, W, fz, zstride, fxy, feat, featB, C, fnorm, F, mult, eps,
+        hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, H, W, fz, zstride, recs, bbox, feat, featB, C, fnorm, F, mult, eps,
                            ntx, nty, lists, counts, out, out_uv, face_idx, normals);
     else
-        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, H, W, fz, zstride, fxy, feat, featB, C, fnorm, F, mult, eps,
+        hipLaunchKernelGGL(k_raster<false>, grid, dim3(256), 0, s, H, W, fz, zstride, recs, bbox, feat, featB, C, fnorm, F, mult, eps,
                            ntx, nty, lists, counts, out, out_uv, face_idx, normals);
     CTX_CHECK_LAUNCH("rasterize");
     return CTX_OK;
@@ -320,23 +336,37 @@ __global__ __launch_bounds__(256) void k_depth_minmax(const float *__restrict__ 
     const float *p = d + (size_t)b * HW;
     float mn = INFINITY, mx = -INFINITY;
     int pos = 0, any = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += ND_BLOCKS * 256) {
-        float v = p[i];
-        if (v > 0.f) pos = 1;
-        if (v != 0.f) { any = 1; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    const int n4 = HW >> 2;
+    const float4 *p4 = (const float4 *)p;            // views start 16-B aligned when HW % 4 == 0 (else scalar path)
+    if ((HW & 3) == 0) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += ND_BLOCKS * 256) {
+            float4 v = p4[i];
+            float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (e[j] > 0.f) pos = 1;
+                if (e[j] != 0.f) { any = 1; mn = fminf(mn, e[j]); mx = fmaxf(mx, e[j]); }
+            }
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += ND_BLOCKS * 256) {
+            float v = p[i];
+            if (v > 0.f) pos = 1;
+            if (v != 0.f) { any = 1; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+        }
     }
     mn = wave_min(mn); mx = wave_max(mx);
     __shared__ float s_mn[4], s_mx[4];
     int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_mn[w] = mn; s_mx[w] = mx; }
-    if (__any(pos) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
-    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
-    __syncthreads();
+    int bpos = __syncthreads_or(pos), bany = __syncthreads_or(any);
     if (threadIdx.x == 0) {
         mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
         mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
         part[((size_t)b * ND_BLOCKS + blockIdx.x) * 2 + 0] = mn;
         part[((size_t)b * ND_BLOCKS + blockIdx.x) * 2 + 1] = mx;
+        // one flag word per block (no same-address atomics): bit0 = positive value seen, bit1 = non-zero seen
+        flags[4 + b * ND_BLOCKS + blockIdx.x] = (bpos ? 1 : 0) | (bany ? 2 : 0);
     }
 }
 
@@ -355,28 +385,44 @@ __global__ __launch_bounds__(256) void k_depth_apply(const float *__restrict__ d
     mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
     mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
     float range = mx - mn;
-    if (status && b == 0 && blockIdx.x == 0 && threadIdx.x == 0)
-        status[0] = flags[0] ? 1 : (flags[1] ? 0 : 2);
+    if (status && b == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int i = threadIdx.x; i < (int)gridDim.y * ND_BLOCKS; i += 256) acc |= flags[4 + i];
+        int any_pos = __syncthreads_or(acc & 1), any_nz = __syncthreads_or(acc & 2);   // returns "any non-zero", not the OR
+        if (threadIdx.x == 0) status[0] = any_pos ? 1 : (any_nz ? 0 : 2);
+    }
     const float *p = d + (size_t)b * HW;
     float *o = out + (size_t)b * HW;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
-        float v = p[i];
-        o[i] = (v != 0.f) ? (v - mn) / range : v;
+    if ((HW & 3) == 0) {
+        const int n4 = HW >> 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+            float4 v = ((const float4 *)p)[i];
+            float4 r;
+            r.x = (v.x != 0.f) ? (v.x - mn) / range : v.x;
+            r.y = (v.y != 0.f) ? (v.y - mn) / range : v.y;
+            r.z = (v.z != 0.f) ? (v.z - mn) / range : v.z;
+            r.w = (v.w != 0.f) ? (v.w - mn) / range : v.w;
+            ((float4 *)o)[i] = r;
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+            float v = p[i];
+            o[i] = (v != 0.f) ? (v - mn) / range : v;
+        }
     }
 }
 
-extern "C" int64_t ctx_normalize_depth_ws_bytes(int32_t B) { return (int64_t)B * ND_BLOCKS * 2 * 4 + 16; }
+extern "C" int64_t ctx_normalize_depth_ws_bytes(int32_t B) { return (int64_t)B * ND_BLOCKS * 3 * 4 + 64; }
 
 extern "C" int32_t ctx_normalize_depth(const float *depth, int32_t B, int32_t HW, float *out, void *ws,
                                        int32_t *status, ctx_stream_t stream)
 {
     CTX_REQUIRE(depth && out && ws && B > 0 && HW > 0, "normalize_depth: bad args");
     hipStream_t s = (hipStream_t)stream;
-    int *flags = (int *)ws;
-    float *part = (float *)ws + 4;
-    (void)hipMemsetAsync(flags, 0, 16, s);
+    int *flags = (int *)ws;                                   // [4 + B*ND_BLOCKS] ints, every word written by pass 1
+    float *part = (float *)ws + 4 + (size_t)B * ND_BLOCKS;
     hipLaunchKernelGGL(k_depth_minmax, dim3(ND_BLOCKS, B), dim3(256), 0, s, depth, HW, part, flags);
-    int nb = min(cdiv(HW, 256), 2048);
+    int nb = min(cdiv(HW, 1024), 1024);
     hipLaunchKernelGGL(k_depth_apply, dim3(nb, B), dim3(256), 0, s, depth, HW, part, flags, out, status);
     CTX_CHECK_LAUNCH("normalize_depth");
     return CTX_OK;
@@ -552,52 +598,53 @@ extern "C" int32_t ctx_view_weights_mask(const int64_t *face_idx, const float *f
 }
 
 // create_face_view_map: ordered stream compaction (count -> scan -> write).
-__global__ __launch_bounds__(256) void k_fvm_count(const int64_t *__restrict__ fi, int64_t N, int *__restrict__ counts)
+#define FVM_BLK 1024
+__global__ __launch_bounds__(FVM_BLK) void k_fvm_count(const int64_t *__restrict__ fi, int64_t N, int *__restrict__ counts)
 {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * FVM_BLK + threadIdx.x;
     bool v = i < N && fi[i] >= 0;
     unsigned long long m = __ballot(v);
-    __shared__ int s[4];
+    __shared__ int s[FVM_BLK / 64];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < FVM_BLK / 64; ++k) t += s[k];
+        counts[blockIdx.x] = t;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_fvm_scan(int *__restrict__ counts, int64_t nblk, int64_t *__restrict__ base,
                                                    int64_t *__restrict__ n_rows)
 {
-    // single workgroup, sequential chunks of 1024 with a running carry
+    // single workgroup: every thread sums one contiguous segment, one Hillis-Steele pass over the 1024 segment sums,
+    // then each thread writes its segment's exclusive prefix
     __shared__ int64_t s[1024];
-    __shared__ int64_t carry;
-    if (threadIdx.x == 0) carry = 0;
+    const int64_t per = (nblk + 1023) / 1024;
+    const int64_t i0 = (int64_t)threadIdx.x * per, i1 = i0 + per < nblk ? i0 + per : nblk;
+    int64_t sum = 0;
+    for (int64_t i = i0; i < i1; ++i) sum += counts[i];
+    s[threadIdx.x] = sum;
     __syncthreads();
-    for (int64_t c0 = 0; c0 < nblk; c0 += 1024) {
-        int64_t i = c0 + threadIdx.x;
-        int64_t v = i < nblk ? counts[i] : 0;
-        s[threadIdx.x] = v;
+    for (int o = 1; o < 1024; o <<= 1) {
+        int64_t t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int64_t t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nblk) base[i] = carry + s[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += s[1023];
+        s[threadIdx.x] += t;
         __syncthreads();
     }
-    if (threadIdx.x == 0) n_rows[0] = carry;
+    int64_t run = s[threadIdx.x] - sum;
+    for (int64_t i = i0; i < i1; ++i) { base[i] = run; run += counts[i]; }
+    if (threadIdx.x == 1023) n_rows[0] = s[1023];
 }
 
-__global__ __launch_bounds__(256) void k_fvm_write(const int64_t *__restrict__ fi, int64_t N, int64_t HW, int W,
+__global__ __launch_bounds__(FVM_BLK) void k_fvm_write(const int64_t *__restrict__ fi, int64_t N, int64_t HW, int W,
                                                    const int64_t *__restrict__ base, int64_t *__restrict__ rows)
 {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * FVM_BLK + threadIdx.x;
     int64_t f = i < N ? fi[i] : -1;
     bool v = f >= 0;
     unsigned long long m = __ballot(v);
-    __shared__ int s[4];
+    __shared__ int s[FVM_BLK / 64];
     int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) s[w] = __popcll(m);
     __syncthreads();
@@ -613,7 +660,7 @@ __global__ __launch_bounds__(256) void k_fvm_write(const int64_t *__restrict__ f
 
 extern "C" int64_t ctx_face_view_map_ws_bytes(int32_t B, int32_t H, int32_t W)
 {
-    int64_t nblk = cdiv64((int64_t)B * H * W, 256);
+    int64_t nblk = cdiv64((int64_t)B * H * W, FVM_BLK);
     return nblk * 4 + nblk * 8 + 64;
 }
 
@@ -622,12 +669,12 @@ extern "C" int32_t ctx_face_view_map(const int64_t *face_idx, int32_t B, int32_t
 {
     CTX_REQUIRE(face_idx && rows && n_rows && ws && B > 0 && H > 0 && W > 0, "face_view_map: bad args");
     hipStream_t s = (hipStream_t)stream;
-    int64_t N = (int64_t)B * H * W, nblk = cdiv64(N, 256);
+    int64_t N = (int64_t)B * H * W, nblk = cdiv64(N, FVM_BLK);
     int64_t *base = (int64_t *)ws;
     int *counts = (int *)(base + nblk);
-    hipLaunchKernelGGL(k_fvm_count, dim3((unsigned)nblk), dim3(256), 0, s, face_idx, N, counts);
+    hipLaunchKernelGGL(k_fvm_count, dim3((unsigned)nblk), dim3(FVM_BLK), 0, s, face_idx, N, counts);
     hipLaunchKernelGGL(k_fvm_scan, dim3(1), dim3(1024), 0, s, counts, nblk, base, n_rows);
-    hipLaunchKernelGGL(k_fvm_write, dim3((unsigned)nblk), dim3(256), 0, s, face_idx, N, (int64_t)H * W, W, base, rows);
+    hipLaunchKernelGGL(k_fvm_write, dim3((unsigned)nblk), dim3(FVM_BLK), 0, s, face_idx, N, (int64_t)H * W, W, base, rows);
     CTX_CHECK_LAUNCH("face_view_map");
     return CTX_OK;
 }
