@@ -153,6 +153,19 @@ def main():
     achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     total_fl = sum(v[1] for v in fl.values())
 
+    # once-per-view tail of img2img_step: VAE decode of the denoised latents (stable_diffusion_depth.py:567), timed outside
+    # the step loop
+    from contexture_nerf_amd.vae import AutoencoderKL
+    vae = AutoencoderKL(device=dev, seed=0)
+    zlat = state["lat"] / 0.18215
+    vae.decode(zlat); torch.cuda.synchronize()
+    tv = time.perf_counter()
+    img = vae.decode(zlat).sample
+    torch.cuda.synchronize()
+    vae_ms = (time.perf_counter() - tv) * 1e3
+    assert torch.isfinite(img).all()
+    vae_tflop = vae.flops() / 1e12
+
     # multi-GPU exchange step of the path (once per mesh, not per denoise step): atlas all-reduce, timed separately
     atlas_ms = None
     if dist is not None:
@@ -175,8 +188,9 @@ def main():
                        "latent": S, "cfg_batch": 2, "ctx_len": 77, "views_per_rank": 1, "parallelism": f"view-shard x{world}"},
             "tflops_per_step": round(total_fl / 1e12, 4),
             "step_tflops_per_s": round(total_fl / 1e12 / (elapsed / a.steps), 2),
-            "sec_per_view_51_evals": round(51 * ms_per_step / 1e3, 3),
-            "sec_per_mesh_6_views_est": round(6 * 51 * ms_per_step / 1e3 / world if world <= 6 else 51 * ms_per_step / 1e3, 3),
+            "vae_decode_ms": round(vae_ms, 3), "vae_decode_tflop": round(vae_tflop, 3),
+            "sec_per_view": round((51 * ms_per_step + vae_ms) / 1e3, 3),
+            "sec_per_mesh_6_views_est": round(-(-6 // world) * (51 * ms_per_step + vae_ms) / 1e3, 3),
             "roofline": {"bound": "mfma", "kernel": "k_gemm_f16 (GEMM + implicit-GEMM conv3x3, v_mfma_f32_32x32x16_f16)",
                          "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
                          "traffic": None, "launches_per_step": gemm_n, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_n, 1), 2),

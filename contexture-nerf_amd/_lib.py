@@ -47,6 +47,17 @@ SIGNATURES = {
     "ctx_unet_set_param": (_i32, [_vp, _i32, _vp, _vp]),
     "ctx_unet_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ctx_unet_stats": (_i32, [_vp, _i32, _vp, _vp]),
+    "ctx_vae_create": (_vp, [_vp]),
+    "ctx_vae_destroy": (None, [_vp]),
+    "ctx_vae_param_count": (_i32, [_vp]),
+    "ctx_vae_param_name": (C.c_char_p, [_vp, _i32]),
+    "ctx_vae_param_shape": (_i32, [_vp, _i32, _vp]),
+    "ctx_vae_weight_bytes": (_i64, [_vp]),
+    "ctx_vae_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
+    "ctx_vae_bind": (_i32, [_vp, _vp, _vp, _i64]),
+    "ctx_vae_set_param": (_i32, [_vp, _i32, _vp, _vp]),
+    "ctx_vae_decode": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "ctx_vae_flops": (C.c_double, [_vp]),
     "ctx_gemm_f16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ctx_conv3x3_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ctx_groupnorm_f16": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
@@ -57,6 +68,7 @@ SIGNATURES = {
     "ctx_geglu_f16": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "ctx_profile_begin": (_i32, []),
     "ctx_profile_end": (_i32, [_i32, _vp, _vp]),
+    "ctx_bench_gemm": (C.c_float, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "ctx_probe_mfma": (_i32, [_i32, _vp, _vp, _vp, _vp]),
     "ctx_cfg_plms_step": (_i32, [_vp, _i64, _f32, _vp, _i32, _vp, _f32, _f32, _i32, _vp, _vp, _vp]),
 }

@@ -629,7 +629,9 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
         auto wgs = [&](int bm, int bn) { return cdiv(a.M, bm) * cdiv(a.N, bn) * S; };
         const bool n128 = (a.N % 128 == 0);
         int pick;
-        if (big && a.M >= 8192 && a.N >= 256 && a.K >= 1024) pick = 0;                 // 256x128, 8 waves
+        static int bigk = -1;
+        if (bigk < 0) { const char *e = getenv("CTX_GEMM_BIGK"); bigk = e ? atoi(e) : 1024; }
+        if (big && a.M >= 8192 && a.N >= 256 && a.K >= bigk) pick = 0;                 // 256x128, 8 waves
         else if (n128 && wgs(128, 128) >= 384) pick = 1;                               // 128x128
         else if (!n128 && wgs(256, 64) >= 384) pick = 2;                               // 256x64
         else if (wgs(128, 64) >= 320) pick = 3;                                        // 128x64, 2 waves
@@ -730,4 +732,39 @@ int ctx_gemv_f16(const f16 *x, const f16 *w, const f16 *bias, int Bm, int N, int
     }
     hipLaunchKernelGGL(k_gemv_f16, dim3(cdiv(N, 4)), dim3(256), 0, s, x, w, bias, Bm, N, K, silu_in, silu_out, out);
     return CTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-timed repeat launcher for tools/bench_gemm.py (the Python call overhead of ~10 us per launch hides the
+// real duration of the small layers).  Returns the average milliseconds per launch, or a negative error code.
+extern "C" float ctx_bench_gemm(const void *A, const void *Wt, const void *bias, const void *residual, int32_t M, int32_t N,
+                                int32_t K, void *C, int32_t conv_B, int32_t conv_H, int32_t conv_W, int32_t conv_Cin,
+                                void *part, int32_t splitk, int32_t iters, ctx_stream_t stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs a = {};
+    a.X = (const f16 *)A; a.Wt = (const f16 *)Wt; a.bias = (const f16 *)bias; a.residual = (const f16 *)residual; a.out = (f16 *)C;
+    bool conv = conv_B > 0;
+    if (conv) {
+        a.H = conv_H; a.W = conv_W; a.Cin = conv_Cin; a.stride = 1; a.ups = 0; a.Ho = conv_H; a.Wo = conv_W;
+        a.M = conv_B * conv_H * conv_W; a.N = N; a.K = 9 * conv_Cin; a.rows_per_batch = conv_H * conv_W;
+    } else {
+        a.M = M; a.N = N; a.K = K; a.rows_per_batch = 1;
+    }
+    a.ldc = a.N; a.ldr = a.N; a.ldrb = a.N; a.epi = 0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < iters + 2; ++i) {
+        if (i == 2) (void)hipEventRecord(e0, s);
+        GemmArgs b = a;
+        b.splitk = splitk; b.part = (float *)part;
+        int rc = ctx_gemm_dispatch(b, conv, s);
+        if (rc) return (float)rc;
+    }
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / iters;
 }

@@ -1,0 +1,343 @@
+// VAE decoder engine: diffusers `AutoencoderKL.decode` (post_quant_conv + Decoder) as used by
+// StableDiffusion.decode_latents (src/stable_diffusion_depth.py:976-990): latents [B,4,h,w] -> image [B,3,8h,8w].
+// Reuses the UNet's fp16 MFMA conv / GEMM and GroupNorm kernels; the single-head (dim 512) mid-block attention is run
+// as two GEMMs around a row softmax (scores are materialised: it is one call per painted view, not per denoise step).
+// Parameter names follow the diffusers AutoencoderKL state_dict ("decoder.up_blocks.2.resnets.0.conv1.weight", ...).
+#include "common.h"
+#include "kernels.h"
+#include <string>
+#include <vector>
+
+struct VParam { std::string name; int ndim; int64_t shape[4]; int kind; size_t dst; int a, b; };   // kind: 0 copy, 1 conv3, 2 convin
+struct VRes { int cin, cout; size_t n1g, n1b, c1w, c1b, n2g, n2b, c2w, c2b, scw, scb; };
+
+struct ctx_vae {
+    ctx_vae_config_t cfg;
+    std::vector<VParam> params;
+    size_t wtop = 0;
+    size_t pqw, pqb, ciw, cib, ang, anb, aqkv, aqkvb, aow, aob, cng, cnb, cow, cob;
+    VRes mid[2];
+    std::vector<std::vector<VRes>> up;
+    std::vector<size_t> upw, upb;
+    std::vector<int> upc;
+    f16 *W = nullptr; char *ws = nullptr; size_t ws_cap = 0, top = 0, peak = 0;
+    bool dry = false; hipStream_t s = nullptr; int rc = 0;
+    double flops = 0;
+
+    size_t walloc(size_t n) { size_t o = wtop; wtop += (n + 127) / 128 * 128; return o; }
+    size_t add(const std::string &name, std::vector<int64_t> shp, int kind, size_t dst, int a = 0, int b = 0)
+    {
+        VParam p; p.name = name; p.ndim = (int)shp.size(); p.kind = kind; p.dst = dst; p.a = a; p.b = b;
+        for (int i = 0; i < 4; ++i) p.shape[i] = i < p.ndim ? shp[i] : 1;
+        params.push_back(p);
+        return dst;
+    }
+    size_t vec(const std::string &n, int c) { return add(n, {c}, 0, walloc(c)); }
+    void *alloc(size_t bytes)
+    {
+        size_t o = (top + 255) / 256 * 256;
+        top = o + bytes;
+        if (top > peak) peak = top;
+        if (!dry && top > ws_cap) { rc = CTX_E_STATE; ctx_set_error("vae: workspace too small (%zu > %zu)", top, ws_cap); return ws; }
+        return dry ? nullptr : (void *)(ws + o);
+    }
+    f16 *allocH(size_t n) { return (f16 *)alloc(n * 2); }
+};
+
+static void vadd_res(ctx_vae *v, const std::string &p, int cin, int cout, VRes &r)
+{
+    r.cin = cin; r.cout = cout;
+    r.n1g = v->vec(p + ".norm1.weight", cin); r.n1b = v->vec(p + ".norm1.bias", cin);
+    r.c1w = v->add(p + ".conv1.weight", {cout, cin, 3, 3}, 1, v->walloc((size_t)cout * cin * 9), cout, cin);
+    r.c1b = v->vec(p + ".conv1.bias", cout);
+    r.n2g = v->vec(p + ".norm2.weight", cout); r.n2b = v->vec(p + ".norm2.bias", cout);
+    r.c2w = v->add(p + ".conv2.weight", {cout, cout, 3, 3}, 1, v->walloc((size_t)cout * cout * 9), cout, cout);
+    r.c2b = v->vec(p + ".conv2.bias", cout);
+    if (cin != cout) {
+        r.scw = v->add(p + ".conv_shortcut.weight", {cout, cin, 1, 1}, 0, v->walloc((size_t)cout * cin));
+        r.scb = v->vec(p + ".conv_shortcut.bias", cout);
+    } else r.scw = r.scb = 0;
+}
+
+extern "C" ctx_vae_t *ctx_vae_create(const ctx_vae_config_t *cfg)
+{
+    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->latent_channels > 8 || cfg->out_channels > 4 || cfg->groups > 64 ||
+        cfg->layers_per_block < 1 || cfg->layers_per_block > 3) { ctx_set_error("vae_create: unsupported config"); return nullptr; }
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->block_out_channels[i] % 64 || cfg->block_out_channels[i] % cfg->groups) { ctx_set_error("vae_create: channels must be multiples of 64 and of groups"); return nullptr; }
+    ctx_vae *v = new ctx_vae();
+    v->cfg = *cfg;
+    const int n = cfg->n_levels, L = cfg->latent_channels;
+    const int *ch = cfg->block_out_channels;
+    const int top = ch[n - 1];
+    if (top % 64) { delete v; return nullptr; }
+    v->pqw = v->add("post_quant_conv.weight", {L, L, 1, 1}, 0, v->walloc((size_t)L * L));
+    v->pqb = v->vec("post_quant_conv.bias", L);
+    v->ciw = v->add("decoder.conv_in.weight", {top, L, 3, 3}, 2, v->walloc((size_t)top * 72), top, L);
+    v->cib = v->vec("decoder.conv_in.bias", top);
+    vadd_res(v, "decoder.mid_block.resnets.0", top, top, v->mid[0]);
+    const std::string ap = "decoder.mid_block.attentions.0";
+    v->ang = v->vec(ap + ".group_norm.weight", top); v->anb = v->vec(ap + ".group_norm.bias", top);
+    v->aqkv = v->walloc((size_t)3 * top * top); v->aqkvb = v->walloc((size_t)3 * top);
+    const char *qkv[3] = {"to_q", "to_k", "to_v"};
+    for (int k = 0; k < 3; ++k) {
+        v->add(ap + "." + qkv[k] + ".weight", {top, top}, 0, v->aqkv + (size_t)k * top * top);
+        v->add(ap + "." + qkv[k] + ".bias", {top}, 0, v->aqkvb + (size_t)k * top);
+    }
+    v->aow = v->add(ap + ".to_out.0.weight", {top, top}, 0, v->walloc((size_t)top * top));
+    v->aob = v->vec(ap + ".to_out.0.bias", top);
+    vadd_res(v, "decoder.mid_block.resnets.1", top, top, v->mid[1]);
+    v->up.resize(n); v->upw.assign(n, 0); v->upb.assign(n, 0); v->upc.assign(n, 0);
+    int out = top;
+    for (int i = 0; i < n; ++i) {
+        int prev = out; out = ch[n - 1 - i];
+        std::string p = "decoder.up_blocks." + std::to_string(i);
+        v->up[i].resize(cfg->layers_per_block + 1);
+        for (int j = 0; j <= cfg->layers_per_block; ++j) vadd_res(v, p + ".resnets." + std::to_string(j), j == 0 ? prev : out, out, v->up[i][j]);
+        if (i != n - 1) {
+            v->upc[i] = out;
+            v->upw[i] = v->add(p + ".upsamplers.0.conv.weight", {out, out, 3, 3}, 1, v->walloc((size_t)out * out * 9), out, out);
+            v->upb[i] = v->vec(p + ".upsamplers.0.conv.bias", out);
+        }
+    }
+    v->cng = v->vec("decoder.conv_norm_out.weight", ch[0]); v->cnb = v->vec("decoder.conv_norm_out.bias", ch[0]);
+    v->cow = v->add("decoder.conv_out.weight", {cfg->out_channels, ch[0], 3, 3}, 1, v->walloc((size_t)cfg->out_channels * ch[0] * 9), cfg->out_channels, ch[0]);
+    v->cob = v->vec("decoder.conv_out.bias", cfg->out_channels);
+    return v;
+}
+
+extern "C" void ctx_vae_destroy(ctx_vae_t *v) { delete v; }
+extern "C" int32_t ctx_vae_param_count(const ctx_vae_t *v) { return v ? (int32_t)v->params.size() : 0; }
+extern "C" const char *ctx_vae_param_name(const ctx_vae_t *v, int32_t i) { return (v && i >= 0 && i < (int)v->params.size()) ? v->params[i].name.c_str() : ""; }
+extern "C" int32_t ctx_vae_param_shape(const ctx_vae_t *v, int32_t i, int64_t shape4[4])
+{
+    if (!v || i < 0 || i >= (int)v->params.size()) return 0;
+    for (int k = 0; k < 4; ++k) shape4[k] = v->params[i].shape[k];
+    return v->params[i].ndim;
+}
+extern "C" int64_t ctx_vae_weight_bytes(const ctx_vae_t *v) { return v ? (int64_t)v->wtop * 2 + 256 : 0; }
+extern "C" int32_t ctx_vae_bind(ctx_vae_t *v, void *weights, void *workspace, int64_t workspace_bytes)
+{
+    CTX_REQUIRE(v && weights && workspace && workspace_bytes > 0, "vae_bind: bad args");
+    v->W = (f16 *)weights; v->ws = (char *)workspace; v->ws_cap = (size_t)workspace_bytes;
+    return CTX_OK;
+}
+
+__global__ void k_vpack_copy(const float *__restrict__ s, int64_t n, f16 *__restrict__ d)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = (f16)s[i];
+}
+__global__ void k_vpack_conv3(const float *__restrict__ s, int Cout, int Cin, int Cinp, f16 *__restrict__ d)
+{
+    int64_t n = (int64_t)Cout * 9 * Cinp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int c = (int)(i % Cinp), tap = (int)((i / Cinp) % 9), o = (int)(i / ((int64_t)Cinp * 9));
+        d[i] = c < Cin ? (f16)s[((int64_t)o * Cin + c) * 9 + tap] : (f16)0.f;
+    }
+}
+extern "C" int32_t ctx_vae_set_param(ctx_vae_t *v, int32_t i, const float *src, ctx_stream_t stream)
+{
+    CTX_REQUIRE(v && v->W && src && i >= 0 && i < (int)v->params.size(), "vae_set_param: bad args / not bound");
+    const VParam &p = v->params[i];
+    int64_t n = 1;
+    for (int k = 0; k < p.ndim; ++k) n *= p.shape[k];
+    unsigned nb = (unsigned)(cdiv64(n, 256) > 4096 ? 4096 : cdiv64(n, 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (p.kind == 0) hipLaunchKernelGGL(k_vpack_copy, dim3(nb), dim3(256), 0, s, src, n, v->W + p.dst);
+    else hipLaunchKernelGGL(k_vpack_conv3, dim3(nb), dim3(256), 0, s, src, p.a, p.b, p.kind == 2 ? 8 : p.b, v->W + p.dst);
+    CTX_CHECK_LAUNCH("vae_set_param");
+    return CTX_OK;
+}
+
+// post_quant_conv: 1x1 conv over <= 8 latent channels, f32 NCHW in/out (16 MACs per pixel)
+__global__ __launch_bounds__(256) void k_pointwise_small(const float *__restrict__ x, const f16 *__restrict__ w, const f16 *__restrict__ b,
+                                                         int B, int C, int64_t HW, float *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * HW; i += (int64_t)gridDim.x * 256) {
+        int bb = (int)(i / HW); int64_t p = i % HW;
+        float in[8];
+        for (int c = 0; c < C; ++c) in[c] = x[((int64_t)bb * C + c) * HW + p];
+        for (int o = 0; o < C; ++o) {
+            float acc = (float)b[o];
+            for (int c = 0; c < C; ++c) acc += in[c] * (float)w[o * C + c];
+            y[((int64_t)bb * C + o) * HW + p] = acc;
+        }
+    }
+}
+
+// row softmax of f16 scores [rows, n] * scale -> f16 probabilities (fp32 math), one workgroup per row
+__global__ __launch_bounds__(256) void k_softmax_rows(const f16 *__restrict__ s, int n, float scale_log2e, f16 *__restrict__ p)
+{
+    const f16 *row = s + (size_t)blockIdx.x * n;
+    f16 *out = p + (size_t)blockIdx.x * n;
+    __shared__ float red[4];
+    float mx = -INFINITY;
+    for (int i = threadIdx.x * 8; i < n; i += 2048) {
+        f16x8 v = *(const f16x8 *)(row + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)v[j]);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2e;
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = threadIdx.x * 8; i < n; i += 2048) {
+        f16x8 v = *(const f16x8 *)(row + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += __builtin_amdgcn_exp2f((float)v[j] * scale_log2e - mx);
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = threadIdx.x * 8; i < n; i += 2048) {
+        f16x8 v = *(const f16x8 *)(row + i);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)(__builtin_amdgcn_exp2f((float)v[j] * scale_log2e - mx) * inv);
+        *(f16x8 *)(out + i) = o;
+    }
+}
+
+#define VRUN(expr) do { if (!v->dry && v->rc == 0) { int r__ = (expr); if (r__ != 0) v->rc = r__; } } while (0)
+
+static void vgemm(ctx_vae *v, const f16 *X, const f16 *Wt, const f16 *bias, const f16 *res, int M, int N, int K, f16 *out)
+{
+    GemmArgs a = {};
+    a.X = X; a.Wt = Wt; a.bias = bias; a.residual = res; a.out = out; a.M = M; a.N = N; a.K = K; a.ldc = N; a.ldr = N;
+    a.rows_per_batch = 1; a.ldrb = N; a.epi = 0;
+    v->flops += 2.0 * M * N * K;
+    size_t mark = v->top;
+    a.splitk = ctx_gemm_pick_split(M, N, K, 0);
+    if (a.splitk > 1) a.part = (float *)v->alloc((size_t)a.splitk * M * N * 4);
+    VRUN(ctx_gemm_dispatch(a, false, v->s));
+    v->top = mark;
+}
+static void vconv(ctx_vae *v, const f16 *x, size_t w, size_t bias, const f16 *res, int B, int H, int W, int Cin, int Cout, int ups, f16 *out)
+{
+    GemmArgs a = {};
+    a.Ho = H << ups; a.Wo = W << ups;
+    a.X = x; a.Wt = v->W + w; a.bias = v->W + bias; a.residual = res; a.out = out;
+    a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Ho * a.Wo; a.ldrb = Cout;
+    a.H = H; a.W = W; a.Cin = Cin; a.stride = 1; a.ups = ups;
+    v->flops += 2.0 * a.M * a.N * a.K;
+    size_t mark = v->top;
+    a.splitk = ctx_gemm_pick_split(a.M, a.N, a.K, 0);
+    if (a.splitk > 1) a.part = (float *)v->alloc((size_t)a.splitk * a.M * a.N * 4);
+    VRUN(ctx_gemm_dispatch(a, true, v->s));
+    v->top = mark;
+}
+static void vgn(ctx_vae *v, const f16 *x, size_t g, size_t b, int B, int HW, int C, int silu, f16 *y, void *stats)
+{
+    VRUN(ctx_groupnorm_f16(x, v->W + g, v->W + b, B, HW, C, v->cfg.groups, 1e-6f, silu, y, stats, v->s));
+}
+static void vres(ctx_vae *v, const VRes &r, const f16 *x, int B, int H, int W, f16 *out, void *stats)
+{
+    const size_t M = (size_t)B * H * W;
+    size_t mark = v->top;
+    f16 *t1 = v->allocH(M * r.cin);
+    vgn(v, x, r.n1g, r.n1b, B, H * W, r.cin, 1, t1, stats);
+    f16 *h = v->allocH(M * r.cout);
+    vconv(v, t1, r.c1w, r.c1b, nullptr, B, H, W, r.cin, r.cout, 0, h);
+    f16 *t2 = v->allocH(M * r.cout);
+    vgn(v, h, r.n2g, r.n2b, B, H * W, r.cout, 1, t2, stats);
+    const f16 *sc = x;
+    if (r.cin != r.cout) {
+        f16 *s2 = v->allocH(M * r.cout);
+        vgemm(v, x, v->W + r.scw, v->W + r.scb, nullptr, (int)M, r.cout, r.cin, s2);
+        sc = s2;
+    }
+    vconv(v, t2, r.c2w, r.c2b, sc, B, H, W, r.cout, r.cout, 0, out);
+    v->top = mark;
+}
+
+static int vae_run(ctx_vae *v, const float *z, int B, int H, int W, float *img)
+{
+    const ctx_vae_config_t &c = v->cfg;
+    const int n = c.n_levels, top = c.block_out_channels[n - 1], L = c.latent_channels;
+    v->top = 0; v->peak = 0; v->rc = 0; v->flops = 0;
+    void *stats = v->alloc((size_t)ctx_groupnorm_ws_bytes(B, c.groups));
+    float *zq = (float *)v->alloc((size_t)B * L * H * W * 4);
+    if (!v->dry) hipLaunchKernelGGL(k_pointwise_small, dim3((unsigned)cdiv64((int64_t)B * H * W, 256)), dim3(256), 0, v->s, z, v->W + v->pqw,
+                                    v->W + v->pqb, B, L, (int64_t)H * W, zq);
+    int h = H, w = W;
+    f16 *x = v->allocH((size_t)B * h * w * top);
+    VRUN(ctx_conv_in_f16(zq, v->W + v->ciw, v->W + v->cib, B, L, h, w, top, x, v->s));
+    f16 *o = v->allocH((size_t)B * h * w * top);
+    vres(v, v->mid[0], x, B, h, w, o, stats);
+    {   // single-head attention, dim = top: q,k,v GEMM -> per-batch scores GEMM -> softmax -> P.V GEMM -> out proj (+residual)
+        const int S = h * w, M = B * S;
+        if (S % 64) { ctx_set_error("vae: latent h*w must be a multiple of 64 (got %d)", S); return CTX_E_ARG; }
+        size_t mark = v->top;
+        f16 *g = v->allocH((size_t)M * top);
+        vgn(v, o, v->ang, v->anb, B, S, top, 0, g, stats);
+        f16 *qkv = v->allocH((size_t)M * 3 * top);
+        vgemm(v, g, v->W + v->aqkv, v->W + v->aqkvb, nullptr, M, 3 * top, top, qkv);
+        f16 *att = v->allocH((size_t)M * top);
+        f16 *sc = v->allocH((size_t)S * S), *pr = v->allocH((size_t)S * S), *vt = v->allocH((size_t)top * S);
+        f16 *qb = v->allocH((size_t)S * top), *kb = v->allocH((size_t)S * top);
+        for (int b = 0; b < B; ++b) {
+            const f16 *base = qkv ? qkv + (size_t)b * S * 3 * top : nullptr;
+            // de-interleave q and k rows (row stride 3*top) into dense [S, top] operands; V^T through the head-transpose kernel
+            if (!v->dry) {
+                (void)hipMemcpy2DAsync(qb, (size_t)top * 2, base, (size_t)3 * top * 2, (size_t)top * 2, S, hipMemcpyDeviceToDevice, v->s);
+                (void)hipMemcpy2DAsync(kb, (size_t)top * 2, base + top, (size_t)3 * top * 2, (size_t)top * 2, S, hipMemcpyDeviceToDevice, v->s);
+            }
+            VRUN(ctx_transpose_v_f16(base + 2 * top, 1, S, 3 * top, top / 64, S, vt, v->s));
+            vgemm(v, qb, kb, nullptr, nullptr, S, S, top, sc);
+            if (!v->dry) hipLaunchKernelGGL(k_softmax_rows, dim3(S), dim3(256), 0, v->s, sc, S, 1.4426950408889634f / sqrtf((float)top), pr);
+            vgemm(v, pr, vt, nullptr, nullptr, S, top, S, att ? att + (size_t)b * S * top : nullptr);
+        }
+        f16 *o2 = v->allocH((size_t)M * top);
+        vgemm(v, att, v->W + v->aow, v->W + v->aob, o, M, top, top, o2);
+        // o2 lives above the mark: copy down into x (free since conv_in's output is dead)
+        if (!v->dry) (void)hipMemcpyAsync(x, o2, (size_t)M * top * 2, hipMemcpyDeviceToDevice, v->s);
+        v->top = mark;
+    }
+    vres(v, v->mid[1], x, B, h, w, o, stats);
+    f16 *cur = o;
+    int cc = top;
+    for (int i = 0; i < n; ++i) {
+        for (size_t j = 0; j < v->up[i].size(); ++j) {
+            int cout = v->up[i][j].cout;
+            f16 *nx = v->allocH((size_t)B * h * w * cout);
+            vres(v, v->up[i][j], cur, B, h, w, nx, stats);
+            cur = nx; cc = cout;
+        }
+        if (i != n - 1) {
+            f16 *nx = v->allocH((size_t)B * (2 * h) * (2 * w) * cc);
+            vconv(v, cur, v->upw[i], v->upb[i], nullptr, B, h, w, cc, cc, 1, nx);
+            cur = nx; h *= 2; w *= 2;
+        }
+    }
+    f16 *y = v->allocH((size_t)B * h * w * cc);
+    vgn(v, cur, v->cng, v->cnb, B, h * w, cc, 1, y, stats);
+    VRUN(ctx_conv_out_f16(y, v->W + v->cow, v->W + v->cob, B, h, w, cc, c.out_channels, img, v->s));
+    if (!v->dry && v->rc == 0) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ctx_set_error("vae_decode: launch failed: %s", hipGetErrorString(e)); return CTX_E_LAUNCH; }
+    }
+    return v->rc;
+}
+
+extern "C" int64_t ctx_vae_workspace_bytes(const ctx_vae_t *cv, int32_t B, int32_t H, int32_t W)
+{
+    ctx_vae *v = const_cast<ctx_vae *>(cv);
+    if (!v || B < 1 || H < 1 || W < 1 || (H * W) % 64) return -1;
+    v->dry = true;
+    vae_run(v, nullptr, B, H, W, nullptr);
+    v->dry = false;
+    return (int64_t)v->peak + 4096;
+}
+
+extern "C" int32_t ctx_vae_decode(ctx_vae_t *v, const float *latents, int32_t B, int32_t H, int32_t W, float *image, ctx_stream_t stream)
+{
+    CTX_REQUIRE(v && latents && image && v->W && v->ws, "vae_decode: null pointer / not bound");
+    CTX_REQUIRE(B >= 1 && H >= 1 && W >= 1 && (H * W) % 64 == 0, "vae_decode: need h*w %% 64 == 0 (B=%d H=%d W=%d)", B, H, W);
+    v->s = (hipStream_t)stream; v->dry = false;
+    return vae_run(v, latents, B, H, W, image);
+}
+
+extern "C" double ctx_vae_flops(const ctx_vae_t *v) { return v ? v->flops : 0.0; }

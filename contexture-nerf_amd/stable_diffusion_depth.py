@@ -4,8 +4,9 @@
 
 Offline facts: no SD2 weights / tokenizer / diffusers => the UNet is the SD2-depth ARCHITECTURE with
 seeded random-init weights (or a local safetensors state_dict passed as `unet_state_dict`), text embeddings come
-from a caller-supplied encoder or are seeded random [2,77,1024], and the VAE ("next") must be
-supplied by the caller; without one `decode_latents` returns a fixed linear latent->RGB preview, flagged as such.
+from a caller-supplied encoder or are seeded random [2,77,1024]; the VAE decoder is the HIP engine of vae.py
+(AutoencoderKL architecture, random-init offline or a local state_dict); the VAE encoder is not built (its output
+is discarded on the reference's live path).
 
 Additions over the reference: `image_size` is a parameter (the reference hard-wires 512, :519) because
 BASELINE.json's configs run 256^2 / 512^2 / 768^2.
@@ -15,10 +16,8 @@ import torch.nn.functional as F
 from . import _lib as L
 from .scheduler import PNDMScheduler
 from .unet import UNet2DConditionModel
+from .vae import AutoencoderKL
 from .utils import seed_everything
-
-# 4->3 linear read-out commonly used to preview SD latents (NOT the VAE; parity-irrelevant placeholder)
-_PREVIEW = torch.tensor([[0.298, 0.207, 0.208], [0.187, 0.286, 0.173], [-0.158, 0.189, 0.264], [-0.184, -0.271, -0.473]])
 
 
 class StableDiffusion:
@@ -39,7 +38,7 @@ class StableDiffusion:
         self.unet = unet if unet is not None else UNet2DConditionModel(device=device, seed=seed, init=unet_state_dict is None)
         if unet_state_dict is not None:
             self.unet.load_state_dict(unet_state_dict)
-        self.vae = vae
+        self.vae = vae if vae is not None else AutoencoderKL(device=device, seed=seed)      # decoder engine (random-init offline)
         self.text_encoder = text_encoder
         self.scheduler = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                                        num_train_timesteps=self.num_train_timesteps, steps_offset=1, skip_prk_steps=True)
@@ -58,16 +57,13 @@ class StableDiffusion:
         return self.scheduler.timesteps[t_start:], num_inference_steps - t_start
 
     def encode_imgs(self, imgs):
-        if self.vae is None:
-            raise L.CtxError("encode_imgs: no VAE supplied (AutoencoderKL is SURVEY §8f n2, not built this round)")
+        if not hasattr(self.vae, 'encode'):
+            raise L.CtxError("encode_imgs: the VAE encoder is not built (the reference's live path discards its result)")
         imgs = 2 * imgs - 1
         return self.vae.encode(imgs).latent_dist.sample() * 0.18215
 
     def decode_latents(self, latents):
         latents = 1 / 0.18215 * latents
-        if self.vae is None:                          # preview only — see module docstring
-            rgb = torch.einsum('bchw,cd->bdhw', latents * 0.18215, _PREVIEW.to(latents.device))
-            return (F.interpolate(rgb, scale_factor=8, mode='nearest') / 2 + 0.5).clamp(0, 1)
         with torch.no_grad():
             imgs = self.vae.decode(latents).sample
         return (imgs / 2 + 0.5).clamp(0, 1)
@@ -107,7 +103,7 @@ class StableDiffusion:
             latents = None
         elif latent_mode:
             latents = inputs
-        elif self.vae is None:
+        elif not hasattr(self.vae, 'encode'):
             # the encoded render only matters when update_mask is None (it is discarded otherwise, see sample()):
             # the reference's live call always passes update_mask, so a zero latent of the right shape is equivalent
             latents = torch.zeros(inputs.shape[0], self.unet.in_channels - 1, image_size // 8, image_size // 8, device=self.device)

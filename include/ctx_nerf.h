@@ -157,6 +157,28 @@ int32_t ctx_unet_forward(ctx_unet_t *u, const float *sample, const float *timest
    (0 gemm/conv MFMA, 1 attention MFMA, 2 other). */
 int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops);
 
+/* ---- VAE decoder (src/stable_diffusion_depth.py:976-990 decode_latents -> diffusers AutoencoderKL.decode) ---------- */
+typedef struct ctx_vae ctx_vae_t;
+typedef struct {
+    int32_t latent_channels, out_channels;
+    int32_t n_levels;                 /* <= 4 */
+    int32_t block_out_channels[4];    /* encoder order, e.g. 128,256,512,512 */
+    int32_t layers_per_block;
+    int32_t groups;
+} ctx_vae_config_t;
+ctx_vae_t *ctx_vae_create(const ctx_vae_config_t *cfg);
+void ctx_vae_destroy(ctx_vae_t *v);
+int32_t ctx_vae_param_count(const ctx_vae_t *v);
+const char *ctx_vae_param_name(const ctx_vae_t *v, int32_t i);      /* diffusers AutoencoderKL state_dict keys */
+int32_t ctx_vae_param_shape(const ctx_vae_t *v, int32_t i, int64_t shape4[4]);
+int64_t ctx_vae_weight_bytes(const ctx_vae_t *v);
+int64_t ctx_vae_workspace_bytes(const ctx_vae_t *v, int32_t B, int32_t H, int32_t W);
+int32_t ctx_vae_bind(ctx_vae_t *v, void *weights, void *workspace, int64_t workspace_bytes);
+int32_t ctx_vae_set_param(ctx_vae_t *v, int32_t i, const float *src, ctx_stream_t stream);
+/* latents [B,L,H,W] f32 (already divided by the 0.18215 scaling factor) -> image [B,3,8H,8W] f32 */
+int32_t ctx_vae_decode(ctx_vae_t *v, const float *latents, int32_t B, int32_t H, int32_t W, float *image, ctx_stream_t stream);
+double ctx_vae_flops(const ctx_vae_t *v);     /* algorithmic FLOPs of the last decode / dry run */
+
 /* Building blocks, exported for unit parity tests (fp16 tensors passed as uint16 bit patterns). */
 /* C[M,N] = A[M,K] @ Wt[N,K]^T (+bias[N]) (+residual[M,N]); K%64==0, N%8==0. */
 int32_t ctx_gemm_f16(const void *A, const void *Wt, const void *bias, const void *residual,
@@ -197,6 +219,12 @@ int32_t ctx_cfg_plms_step(const float *eps_pair, int64_t n, float guidance, floa
    end() synchronises them and returns the summed kernel time and the launch count of one class. */
 int32_t ctx_profile_begin(void);
 int32_t ctx_profile_end(int32_t klass, double *total_ms /*host*/, int64_t *count /*host*/);
+
+/* Benchmark support (tools/bench_gemm.py): `iters` back-to-back launches timed on the device; conv_B > 0 selects the
+   implicit-GEMM conv (N = Cout, input [conv_B, conv_H, conv_W, conv_Cin]).  Returns average ms per launch (< 0: error). */
+float ctx_bench_gemm(const void *A, const void *Wt, const void *bias, const void *residual, int32_t M, int32_t N, int32_t K,
+                     void *C, int32_t conv_B, int32_t conv_H, int32_t conv_W, int32_t conv_Cin, void *part, int32_t splitk,
+                     int32_t iters, ctx_stream_t stream);
 
 /* Unit-test support: one 32x32 tile through the MFMA fragment maps the kernels assume.
    which 0: f16 32x32x16 (A[32][16], Bt[32][16]); 1: f32 32x32x2 (A[32][2], Bt[32][2]); C[32][32] f32. */

@@ -68,6 +68,15 @@ def test_unet_param_table_matches_diffusers_naming():
         assert abs(total - unet_ref.count_flops(unet_ref.SD2_DEPTH, hw, hw)['total']) / want < 1e-6
 
 
+def test_vae_param_table_matches_diffusers_naming():
+    from contexture_nerf_amd.vae import AutoencoderKL
+    from oracle import vae_ref
+    v = AutoencoderKL(device="cpu", init=False)
+    r = vae_ref.AutoencoderKLDecodeRef()
+    assert v.param_shapes() == {k: tuple(t.shape) for k, t in r.state_dict().items()}
+    assert 49e6 < sum(t.numel() for t in r.parameters()) < 50e6
+
+
 def test_size_queries():
     from contexture_nerf_amd import _lib as L
     lib = L.load()

@@ -225,3 +225,25 @@ def test_unet_sd2_depth_shapes_and_determinism(dev):
     assert a.shape == (2, 4, 32, 32) and torch.isfinite(a).all()
     assert torch.equal(a, b)
     assert a.std() > 1e-3
+
+
+@pytest.mark.parametrize("cfgname,h,w", [("tiny", 8, 8), ("tiny", 16, 8), ("sd", 8, 8)])
+def test_vae_decode_vs_oracle(dev, cfgname, h, w):
+    """VAE decoder engine vs the oracle's fp32 AutoencoderKL.decode restatement (random init, affines perturbed)."""
+    from contexture_nerf_amd.vae import AutoencoderKL
+    from oracle import vae_ref, unet_ref
+    cfg = dict(vae_ref.SD_VAE) if cfgname == "sd" else dict(latent_channels=4, out_channels=3, block_out_channels=(64, 128), layers_per_block=1, groups=32)
+    torch.manual_seed(3)
+    ref = unet_ref.randomize_affine(vae_ref.AutoencoderKLDecodeRef(cfg)).eval()
+    vae = AutoencoderKL(cfg, device=dev, init=False)
+    vae.load_state_dict(ref.state_dict())
+    z = torch.randn(1, 4, h, w)
+    with torch.no_grad():
+        want = ref.decode(z)
+    got = vae.decode(z.to(dev)).sample
+    up = 2 ** (len(cfg['block_out_channels']) - 1)
+    assert got.shape == (1, 3, h * up, w * up) and torch.isfinite(got).all()
+    r = _rel(got, want)
+    print(f"vae {cfgname} {h}x{w}: rel L2 vs fp32 = {r:.3e}")
+    assert r < 3e-3, r            # same fp16-storage noise floor as the UNet (tests/test_precision_cpu.py)
+    assert torch.equal(got, vae.decode(z.to(dev)).sample)

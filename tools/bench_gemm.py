@@ -17,9 +17,39 @@ shapes = [("conv", (2, 96, 96), 320, 320), ("conv", (2, 48, 48), 640, 640), ("co
           ("conv", (2, 24, 24), 1280, 2560), ("conv", (2, 96, 96), 320, 960),
           ("gemm", 18432, 320, 320), ("gemm", 18432, 960, 320), ("gemm", 18432, 2560, 320), ("gemm", 18432, 320, 1280),
           ("gemm", 4608, 640, 640), ("gemm", 4608, 5120, 640), ("gemm", 4608, 640, 2560),
-          ("gemm", 1152, 1280, 1280), ("gemm", 1152, 10240, 1280), ("gemm", 1152, 1280, 5120), ("gemm", 154, 640, 1024)]
+          ("gemm", 1152, 1280, 1280), ("gemm", 1152, 10240, 1280), ("gemm", 1152, 1280, 5120), ("gemm", 154, 640, 1024),
+          ("gemm", 18432, 320, 32), ("gemm", 18432, 320, 64), ("gemm", 18432, 320, 128), ("gemm", 18432, 320, 640),
+          ("gemm", 18432, 128, 320), ("gemm", 18432, 640, 320), ("gemm", 4608, 320, 320), ("gemm", 36864, 320, 320)]
 if only is not None:
     shapes = [shapes[i] for i in only]
+g = torch.Generator(device=dev).manual_seed(0)
+with_res = os.environ.get("BENCH_RES", "0") == "1"
+tot_fl = tot_ms = 0
+for s_ in shapes:
+    if s_[0] == "conv":
+        (B, H, W), N, Cin = s_[1], s_[2], s_[3]
+        M, K = B * H * W, 9 * Cin
+        x = torch.randn(B, H, W, Cin, generator=g, device=dev).half()
+        cb = (B, H, W, Cin)
+    else:
+        M, N, K = s_[1], s_[2], s_[3]
+        x = torch.randn(M, K, generator=g, device=dev).half()
+        cb = (0, 0, 0, 0)
+    w = (torch.randn(N, K, generator=g, device=dev) / K ** 0.5).half()
+    y = torch.empty(M, N, dtype=torch.float16, device=dev)
+    res = torch.randn(M, N, generator=g, device=dev).half() if with_res else None
+    bias = torch.randn(N, generator=g, device=dev).half() if with_res else None
+    fl = 2.0 * M * N * K
+    times = []
+    for r_ in range(rounds):
+        ms = lib.ctx_bench_gemm(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(res), M, N, K, L.ptr(y), *cb, None, 1, 20, L.stream())
+        assert ms > 0, lib.ctx_last_error()
+        times.append(ms)
+    ms = sorted(times)[len(times) // 2]
+    tot_fl += fl; tot_ms += ms
+    print(f"{str(s_):45s} {fl / 1e9:9.2f} GFLOP  median {ms * 1e3:8.1f} us  {fl / ms / 1e9:8.1f} TFLOP/s  (min {min(times) * 1e3:.1f} us)")
+print(f"tile={os.environ.get('CTX_GEMM_TILE', 'auto')} res={with_res}  sum: {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
+sys.exit(0)
 g = torch.Generator(device=dev).manual_seed(0)
 items = []
 for s in shapes:
