@@ -390,7 +390,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
         wp[i] = ok ? a.Wt + (size_t)(n0 + row) * a.K + kbeg * PKT + ((pc ^ (PKT == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7))) * 8) : g_zero_page;
         wst[i] = ok ? PKT : 0;
     }
-    int k_issue = kbeg * PKT, issued = 0, tap_left = 0;
+    // K rotation: workgroups that stream the same weight rows (same tile_n) or the same activation rows (same tile_m)
+    // start at different K offsets and wrap, so at any instant they hit different cache lines / L2 channels.
+    const int k_lo = kbeg * PKT, k_hi = (kbeg + nk) * PKT;
+    const int rot = a.krot ? (int)(((unsigned)tile_m * 13u + (unsigned)tile_n * 5u) % (unsigned)nk) : 0;
+    int k_issue = k_lo + rot * PKT, issued = 0, tap_left = 0;
+    if (!CONV) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) xp[i] += (xst[i] ? rot * PKT : 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) wp[i] += (wst[i] ? rot * PKT : 0);
 
     auto retap = [&]() {                            // CONV: new 3x3 tap -> recompute the activation pointers
         int tap = k_issue / a.Cin, c0 = k_issue - tap * a.Cin;
@@ -406,6 +416,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
         tap_left = (a.Cin - c0) / PKT;
     };
     auto issue = [&](int buf) {
+        if (k_issue == k_hi) {                       // wrap of the rotated K range
+            k_issue = k_lo;
+            const int span = k_hi - k_lo;
+            if (!CONV) {
+#pragma unroll
+                for (int i = 0; i < XI; ++i) xp[i] -= (xst[i] ? span : 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WI; ++i) wp[i] -= (wst[i] ? span : 0);
+            tap_left = 0;
+        }
         if (CONV) {
             if (tap_left == 0) retap();
             --tap_left;
@@ -552,6 +573,9 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
             go(k_gemm_pipe<WM, WN, CONV, 3, 64>, (size_t)3 * (BM + BN) * 64 * sizeof(f16), d64);
         } else {
             a.pk = 32;
+            static int krot = -1;
+            if (krot < 0) { const char *e = getenv("CTX_GEMM_KROT"); krot = e ? atoi(e) : 0; }
+            a.krot = krot;
             static bool d32 = false;
             // deeper rings for the small tiles: a 1- or 2-wave workgroup needs more bytes in flight to pull its share
             constexpr int NSD = (WM * WN == 1) ? 8 : (WM * WN == 2 ? 6 : 4);

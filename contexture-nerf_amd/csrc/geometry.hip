@@ -738,58 +738,81 @@ extern "C" int32_t ctx_get_rays(int32_t H, int32_t W, float fx, float fy, float 
 }
 
 // One wavefront per ray: lane s holds sample s of the current 64-sample chunk.  Transmittance is an
-// exclusive prefix product across lanes (6 shuffle steps), colour/depth/acc are wave sums.
+// exclusive prefix product across lanes (6 shuffle steps), colour/depth/acc are wave sums.  The next chunk's (or next
+// ray's first) loads are issued before the current chunk is reduced, so HBM latency overlaps the shuffle chain.
 __global__ __launch_bounds__(256) void k_composite(const float4 *__restrict__ raw, const float *__restrict__ z,
                                                    const float *__restrict__ rays_d, int64_t R, int S, int white,
                                                    float *__restrict__ rgb, float *__restrict__ disp,
                                                    float *__restrict__ acc, float *__restrict__ weights,
                                                    float *__restrict__ depth)
 {
-    int lane = threadIdx.x & 63;
-    int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-    int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
-    for (int64_t r = wave; r < R; r += nwaves) {
-        float d0 = rays_d[r * 3 + 0], d1 = rays_d[r * 3 + 1], d2 = rays_d[r * 3 + 2];
-        float nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
-        float Tc = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, a = 0.f;
-        for (int s0 = 0; s0 < S; s0 += 64) {
-            int s = s0 + lane;
-            bool ok = s < S;
-            float4 q = ok ? raw[r * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
-            float zv = ok ? z[r * S + s] : 0.f;
-            float zn = (s + 1 < S) ? z[r * S + s + 1] : 0.f;
-            float dist = (s + 1 < S) ? (zn - zv) : 1e10f;
-            dist = dist * nrm;
-            float sigma = q.w > 0.f ? q.w : 0.f;
-            float alpha = ok ? 1.0f - expf(-sigma * dist) : 0.f;
-            float t = ok ? (1.0f - alpha) + 1e-10f : 1.0f;
-            // inclusive prefix product
-            float inc = t;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    const int nch = (S + 63) >> 6;
+    // software pipeline over the flattened (ray, chunk) sequence of this wave
+    int64_t r = wave;
+    int ch = 0;
+    float4 q_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    float z_n = 0.f, zx_n = 0.f;
+    auto fetch = [&](int64_t rr, int cc) {
+        int s = cc * 64 + lane;
+        bool ok = rr < R && s < S;
+        q_n = ok ? raw[rr * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        z_n = ok ? z[rr * S + s] : 0.f;
+        zx_n = (rr < R && lane == 63 && s + 1 < S) ? z[rr * S + s + 1] : 0.f;      // first depth of the following chunk
+    };
+    if (r < R) fetch(r, 0);
+    float Tc = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, a = 0.f, nrm = 0.f;
+    while (r < R) {
+        float4 q = q_n;
+        float zv = z_n, zx = zx_n;
+        const int s = ch * 64 + lane;
+        const bool ok = s < S;
+        if (ch == 0) {
+            float d0 = rays_d[r * 3 + 0], d1 = rays_d[r * 3 + 1], d2 = rays_d[r * 3 + 2];
+            nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+            Tc = 1.0f; c0 = c1 = c2 = dep = a = 0.f;
+        }
+        // issue the next (ray, chunk) loads now
+        int64_t rn = r; int cn = ch + 1;
+        if (cn == nch) { cn = 0; rn = r + nwaves; }
+        fetch(rn, cn);
+        float zn = __shfl_down(zv, 1, 64);
+        if (lane == 63) zn = zx;
+        float dist = (s + 1 < S) ? (zn - zv) : 1e10f;
+        dist = dist * nrm;
+        float sigma = q.w > 0.f ? q.w : 0.f;
+        float alpha = ok ? 1.0f - __builtin_amdgcn_exp2f(-1.4426950408889634f * sigma * dist) : 0.f;
+        float t = ok ? (1.0f - alpha) + 1e-10f : 1.0f;
+        float inc = t;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                float up = __shfl_up(inc, o, 64);
-                if (lane >= o) inc = inc * up;
+        for (int o = 1; o < 64; o <<= 1) {
+            float up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc = inc * up;
+        }
+        float exc = __shfl_up(inc, 1, 64);
+        if (lane == 0) exc = 1.0f;
+        float w = alpha * (Tc * exc);
+        if (weights && ok) weights[r * S + s] = w;
+        c0 += w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * q.x));
+        c1 += w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * q.y));
+        c2 += w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * q.z));
+        dep += w * zv;
+        a += w;
+        Tc = Tc * __shfl(inc, 63, 64);
+        if (ch + 1 == nch) {
+            float s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2), sd = wave_sum(dep), sa = wave_sum(a);
+            if (lane == 0) {
+                if (white) { s0 += 1.0f - sa; s1 += 1.0f - sa; s2 += 1.0f - sa; }
+                rgb[r * 3 + 0] = s0; rgb[r * 3 + 1] = s1; rgb[r * 3 + 2] = s2;
+                depth[r] = sd; acc[r] = sa;
+                float qd = sd / sa;
+                float dv = 1.0f / (qd > 1e-10f ? qd : 1e-10f);
+                disp[r] = (qd != qd) ? qd : dv;
             }
-            float exc = __shfl_up(inc, 1, 64);
-            if (lane == 0) exc = 1.0f;
-            float w = alpha * (Tc * exc);
-            if (weights && ok) weights[r * S + s] = w;
-            c0 += w * (1.0f / (1.0f + expf(-q.x)));
-            c1 += w * (1.0f / (1.0f + expf(-q.y)));
-            c2 += w * (1.0f / (1.0f + expf(-q.z)));
-            dep += w * zv;
-            a += w;
-            Tc = Tc * __shfl(inc, 63, 64);
         }
-        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); dep = wave_sum(dep); a = wave_sum(a);
-        if (lane == 0) {
-            if (white) { c0 += 1.0f - a; c1 += 1.0f - a; c2 += 1.0f - a; }
-            rgb[r * 3 + 0] = c0; rgb[r * 3 + 1] = c1; rgb[r * 3 + 2] = c2;
-            depth[r] = dep; acc[r] = a;
-            float qd = dep / a;
-            float dv = 1.0f / (qd > 1e-10f ? qd : 1e-10f);
-            disp[r] = (qd != qd) ? qd : dv;
-        }
+        r = rn; ch = cn;
     }
 }
 

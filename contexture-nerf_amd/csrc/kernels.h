@@ -20,6 +20,7 @@ struct GemmArgs {
     int splitk;            // >1: grid.y = splitk, fp32 partials [splitk][M][N] go to `part`
     float *part;
     int pk;                // K-stage depth chosen by the launcher (32 or 64)
+    int krot;              // 1: per-workgroup K rotation (spreads concurrent accesses to shared operand rows)
 };
 
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s);
