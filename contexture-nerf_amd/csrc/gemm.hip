@@ -349,14 +349,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int bid = xcd_remap(blockIdx.x, a.ntm * a.ntn);
-    const int tile_n = bid % a.ntn, tile_m = bid / a.ntn;
+    // 1-D grid of tiles x K-slices, slice-major, cut into 8 contiguous runs (one per XCD: blocks b and b+8 share an L2):
+    // an XCD then streams ~1/8 of the K range of both operands.  Inside a slice the tile order walks the operand that is
+    // re-read most (mfast: consecutive blocks share the weight panel; else the activation panel).
+    const int ntiles = a.ntm * a.ntn;
+    const int lin = xcd_remap(blockIdx.x, ntiles * a.splitk);
+    const int slice = lin / ntiles, bid = lin - slice * ntiles;
+    const int tile_n = a.mfast ? bid / a.ntm : bid % a.ntn, tile_m = a.mfast ? bid % a.ntm : bid / a.ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int lr = lane / LPR, pc = lane % LPR;        // row within the piece's 16 rows, physical 16-B chunk
 
     const int nk_all = a.K / PKT;
-    const int kbeg = (int)((long)nk_all * blockIdx.y / a.splitk);
-    const int nk = (int)((long)nk_all * (blockIdx.y + 1) / a.splitk) - kbeg;
+    const int kbeg = (int)((long)nk_all * slice / a.splitk);
+    const int nk = (int)((long)nk_all * (slice + 1) / a.splitk) - kbeg;
 
     // ---- issue-side state: one running source pointer per DMA piece (advanced by a fixed step per stage; rows that
     // are out of range / conv padding point at a zero page with step 0), so a stage costs G loads + G pointer adds
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
         }
     }
     if (a.splitk > 1) {
-        float *pb = a.part + (size_t)blockIdx.y * a.M * a.N;
+        float *pb = a.part + (size_t)slice * a.M * a.N;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             int m = m0 + wm * 64 + mi * 32 + r;
@@ -552,6 +557,11 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
     const int impl = gemm_impl();
     if (a.splitk < 1 || !a.part || impl != 2) a.splitk = 1;
     if (impl == 2) {
+        static int mfast = -2;
+        if (mfast == -2) { const char *e = getenv("CTX_GEMM_MFAST"); mfast = e ? atoi(e) : -1; }
+        // unique operand bytes: weights N*K vs activations M*K (conv: M*Cin, the 9 taps re-read the same pixels)
+        const double wbytes = (double)a.N * a.K, xbytes = (double)a.M * (CONV ? a.Cin : a.K);
+        a.mfast = mfast >= 0 ? mfast : (wbytes > xbytes ? 1 : 0);
         static int pk64 = -1;
         if (pk64 < 0) { const char *e = getenv("CTX_GEMM_PK"); pk64 = (e && atoi(e) == 64) ? 1 : 0; }
         constexpr int NT = 64 * WM * WN;
@@ -563,9 +573,9 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
             if (ctx_prof_on()) {
                 hipEvent_t e0, e1;
                 ctx_prof_events(0, &e0, &e1);
-                hipExtLaunchKernelGGL(kern, dim3(a.ntm * a.ntn, a.splitk), dim3(NT), lds, s, e0, e1, 0, a);
+                hipExtLaunchKernelGGL(kern, dim3(a.ntm * a.ntn * a.splitk), dim3(NT), lds, s, e0, e1, 0, a);
             } else
-                hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn, a.splitk), dim3(NT), lds, s, a);
+                hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn * a.splitk), dim3(NT), lds, s, a);
         };
         if (pk64 && a.K % 64 == 0 && (!CONV || a.Cin % 64 == 0)) {
             a.pk = 64;
@@ -640,7 +650,18 @@ int ctx_gemm_pick_split(int M, int N, int K, int epi)
 // Tile choice: 128x128 when N is a multiple of 128 (no masked columns), else 256x64.
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
 {
-    if (gemm_impl() != 2) {                          // legacy kernels: 4-wave tiles only
+    if (gemm_impl() == 2 && ctx_gemm8_try(a, conv, s)) {
+        if (a.splitk > 1) {
+            size_t total = (size_t)a.M * (a.N / 4);
+            unsigned nb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+            if (ctx_prof_on()) {
+                hipEvent_t e0, e1;
+                ctx_prof_events(0, &e0, &e1);
+                hipExtLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, e0, e1, 0, a);
+            } else
+                hipLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, a);
+        }
+    } else if (gemm_impl() != 2) {                   // legacy kernels: 4-wave tiles only
         bool wide = (a.N % 128 == 0) && a.epi == 0;
         if (conv) { if (wide) launch_gemm<2, 2, true>(a, s); else launch_gemm<4, 1, true>(a, s); }
         else { if (wide) launch_gemm<2, 2, false>(a, s); else launch_gemm<4, 1, false>(a, s); }
@@ -763,19 +784,23 @@ int ctx_gemv_f16(const f16 *x, const f16 *w, const f16 *bias, int Bm, int N, int
 // real duration of the small layers).  Returns the average milliseconds per launch, or a negative error code.
 extern "C" float ctx_bench_gemm(const void *A, const void *Wt, const void *bias, const void *residual, int32_t M, int32_t N,
                                 int32_t K, void *C, int32_t conv_B, int32_t conv_H, int32_t conv_W, int32_t conv_Cin,
-                                void *part, int32_t splitk, int32_t iters, ctx_stream_t stream)
+                                int32_t conv_flags, int32_t epi, void *part, int32_t splitk, int32_t iters, ctx_stream_t stream)
 {
     hipStream_t s = (hipStream_t)stream;
     GemmArgs a = {};
     a.X = (const f16 *)A; a.Wt = (const f16 *)Wt; a.bias = (const f16 *)bias; a.residual = (const f16 *)residual; a.out = (f16 *)C;
     bool conv = conv_B > 0;
     if (conv) {
-        a.H = conv_H; a.W = conv_W; a.Cin = conv_Cin; a.stride = 1; a.ups = 0; a.Ho = conv_H; a.Wo = conv_W;
-        a.M = conv_B * conv_H * conv_W; a.N = N; a.K = 9 * conv_Cin; a.rows_per_batch = conv_H * conv_W;
+        a.stride = (conv_flags & 1) ? 2 : 1; a.ups = (conv_flags & 2) ? 1 : 0;
+        int Hv = conv_H << a.ups, Wv = conv_W << a.ups;
+        a.H = conv_H; a.W = conv_W; a.Cin = conv_Cin; a.Ho = (Hv - 1) / a.stride + 1; a.Wo = (Wv - 1) / a.stride + 1;
+        a.M = conv_B * a.Ho * a.Wo; a.N = N; a.K = 9 * conv_Cin; a.rows_per_batch = a.Ho * a.Wo;
     } else {
         a.M = M; a.N = N; a.K = K; a.rows_per_batch = 1;
     }
-    a.ldc = a.N; a.ldr = a.N; a.ldrb = a.N; a.epi = 0;
+    a.epi = epi;
+    a.ldc = epi == 1 ? a.N / 2 : a.N; a.ldr = a.N; a.ldrb = a.N;
+    if (splitk < 0) splitk = part ? ctx_gemm_pick_split(a.M, a.N, a.K, epi) : 1;      // what the UNet executor would choose
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < iters + 2; ++i) {

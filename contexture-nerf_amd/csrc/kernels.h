@@ -21,9 +21,12 @@ struct GemmArgs {
     float *part;
     int pk;                // K-stage depth chosen by the launcher (32 or 64)
     int krot;              // 1: per-workgroup K rotation (spreads concurrent accesses to shared operand rows)
+    int mfast;             // 1: consecutive workgroups walk M first (share the weight panel in their XCD's L2)
 };
 
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s);
+// 256x256 8-wave kernel (gemm8.hip): launches and returns 1 when the problem suits it, else 0
+int ctx_gemm8_try(GemmArgs &a, bool conv, hipStream_t s);
 // split-K factor the dispatcher would use for this problem (1 = none); caller provides a.part = S*M*N floats
 int ctx_gemm_pick_split(int M, int N, int K, int epi);
 int ctx_gemv_f16(const f16 *x, const f16 *w, const f16 *bias, int Bm, int N, int K, int silu_in, int silu_out, f16 *out, hipStream_t s);

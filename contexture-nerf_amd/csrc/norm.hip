@@ -9,18 +9,23 @@
 #include <math.h>
 
 // ------------------------------------------------------------------------------------------------
-// GroupNorm.  Pass 1: grid (NS, B); thread (c8, pl) owns 8 channels, walks pixels pl, pl+PL, ...
-// of its split, keeps per-channel sum/sumsq in registers, folds them into per-group LDS bins once.
-// Pass 2 reduces the NS partials per (b, group) on the fly and applies  (x-mean)*rstd*gamma+beta (+SiLU).
+// GroupNorm.  Both passes are latency-bound at the UNet's sizes (a 12 MB tensor is ~2 HBM latencies deep), so the
+// structure is "every load of a thread in flight at once":
+// Pass 1: grid (NS, B), block = C/8 chunk columns x PL pixel lanes (~1000 threads); a thread owns 8 channels and
+// up to GN_U pixels of its split, all loaded before the first add; per-channel partials -> LDS -> per-group sums.
+// Pass 2: grid (nb, B); a thread issues its GN_AU 16-byte loads first, then the block folds the NS split partials
+// per (b, group) in a fixed order (deterministic: no float atomics anywhere in GroupNorm) while they fly.
 #define GN_MAX_GROUPS 64
+#define GN_MAX_SPLITS 128
+#define GN_MAX_C 4096
+#define GN_U 4
+#define GN_AU 4
 
-__global__ void k_gn_stats(const f16 *__restrict__ x, int HW, int C, int G, int NS, float *__restrict__ part)
+__global__ __launch_bounds__(1024) void k_gn_stats(const f16 *__restrict__ x, int HW, int C, int G, int NS, int PL,
+                                                   float *__restrict__ part)
 {
-    // deterministic: per-thread channel partials go to LDS [pl][C][2]; thread g then sums its group's
-    // channels over all pixel lanes in a fixed order (no float atomics anywhere in GroupNorm).
-    extern __shared__ float s_part[];
+    extern __shared__ float s_part[];          // [PL][C][2]
     const int c8n = C / 8;
-    const int PL = blockDim.x / c8n;
     const int b = blockIdx.y, sp = blockIdx.x;
     const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
     const int per = (HW + NS - 1) / NS;
@@ -29,10 +34,17 @@ __global__ void k_gn_stats(const f16 *__restrict__ x, int HW, int C, int G, int 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
     const f16 *base = x + ((size_t)b * HW) * C + c8 * 8;
-    for (int p = p0 + pl; p < p1; p += PL) {
-        f16x8 v = *(const f16x8 *)(base + (size_t)p * C);
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = p0 + pl; p < p1; p += PL * GN_U) {
+        f16x8 v[GN_U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+        for (int u = 0; u < GN_U; ++u) v[u] = *(const f16x8 *)(base + (size_t)min(p + u * PL, p1 - 1) * C);   // unconditional
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            if (p + u * PL >= p1) v[u] = zero8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -40,21 +52,43 @@ __global__ void k_gn_stats(const f16 *__restrict__ x, int HW, int C, int G, int 
         s_part[((size_t)pl * C + c8 * 8 + j) * 2 + 1] = q[j];
     }
     __syncthreads();
-    const int cg = C / G;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    // fixed-order fold, two short steps.  A: (channel, slice a of the pixel lanes) -> s_ch[a][C]; B: 8 lanes per group
+    // walk that group's na x cg cells, then a shuffle tree.
+    float *s_ch = s_part + (size_t)PL * C * 2;
+    const int na = max(1, (int)blockDim.x / C);
+    for (int it = threadIdx.x; it < C * na; it += blockDim.x) {
+        const int a = it / C, c = it - a * C;
         float ss = 0.f, qq = 0.f;
-        for (int l = 0; l < PL; ++l)
-            for (int c = g * cg; c < (g + 1) * cg; ++c) {
-                ss += s_part[((size_t)l * C + c) * 2 + 0];
-                qq += s_part[((size_t)l * C + c) * 2 + 1];
+#pragma unroll 4
+        for (int l = a; l < PL; l += na) {
+            ss += s_part[((size_t)l * C + c) * 2 + 0];
+            qq += s_part[((size_t)l * C + c) * 2 + 1];
+        }
+        s_ch[((size_t)a * C + c) * 2 + 0] = ss;
+        s_ch[((size_t)a * C + c) * 2 + 1] = qq;
+    }
+    __syncthreads();
+    const int cg = C / G, cells = na * cg;
+    const int octs = (int)blockDim.x >> 3;               // whole 8-lane groups only
+    for (int g0 = 0; g0 < G; g0 += octs) {
+        const int oc = (int)threadIdx.x >> 3, l = threadIdx.x & 7;
+        const int g = oc < octs ? g0 + oc : G;
+        float ss = 0.f, qq = 0.f;
+        if (g < G)
+            for (int k = l; k < cells; k += 8) {
+                int a = k / cg, c = g * cg + (k - a * cg);
+                ss += s_ch[((size_t)a * C + c) * 2 + 0];
+                qq += s_ch[((size_t)a * C + c) * 2 + 1];
             }
-        part[(((size_t)b * NS + sp) * G + g) * 2 + 0] = ss;
-        part[(((size_t)b * NS + sp) * G + g) * 2 + 1] = qq;
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); qq += __shfl_xor(qq, o, 64); }
+        if (g < G && l == 0) {
+            part[(((size_t)b * NS + sp) * G + g) * 2 + 0] = ss;
+            part[(((size_t)b * NS + sp) * G + g) * 2 + 1] = qq;
+        }
     }
 }
 
-// apply: every block first folds the (<= GN_MAX_SPLITS) split partials into mean / rstd per group in a fixed order
-// (8 lanes per group + shuffle tree), builds the per-channel affine y = x*sa + sb in LDS, then streams its pixels.
 __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, const float *__restrict__ part,
                                                   const f16 *__restrict__ gamma, const f16 *__restrict__ beta, int HW, int C,
                                                   int G, int NS, float eps, int silu, f16 *__restrict__ y)
@@ -62,14 +96,39 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
     extern __shared__ float s_ab[];          // [2][C]
     __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
     const int b = blockIdx.y;
+    const int c8n = C / 8;
+    const f16 *xb = x + (size_t)b * HW * C;
+    f16 *yb = y + (size_t)b * HW * C;
+    const unsigned total = (unsigned)HW * (unsigned)c8n;
+    const unsigned i0 = blockIdx.x * (256u * GN_AU) + threadIdx.x;
+    f16x8 v[GN_AU];
+#pragma unroll
+    for (int u = 0; u < GN_AU; ++u) {
+        unsigned i = min(i0 + 256u * u, total - 1u);                       // unconditional: no branch, no early wait
+        v[u] = *(const f16x8 *)(xb + (size_t)i * 8);                        // in flight during the fold below
+    }
+    // per-channel affine inputs and this lane's share of the split partials: every load issued before the first use
+    float gm[GN_MAX_C / 256], bt[GN_MAX_C / 256];
+#pragma unroll
+    for (int k = 0; k < GN_MAX_C / 256; ++k) {
+        int c = min((int)threadIdx.x + 256 * k, C - 1);
+        gm[k] = (float)gamma[c];
+        bt[k] = (float)beta[c];
+    }
     {
         const int lpg = 256 / G;
         const int g = threadIdx.x / lpg, l = threadIdx.x % lpg;
-        float s = 0.f, q = 0.f;
-        for (int k = l; k < NS; k += lpg) {
-            s += part[(((size_t)b * NS + k) * G + g) * 2 + 0];
-            q += part[(((size_t)b * NS + k) * G + g) * 2 + 1];
+        constexpr int MAXK = GN_MAX_SPLITS * GN_MAX_GROUPS / 256;          // partials per lane, worst case
+        float2 pv[MAXK];
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            int sp = min(l + k * lpg, NS - 1);
+            pv[k] = *(const float2 *)(part + (((size_t)b * NS + sp) * G + g) * 2);
         }
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (l + k * lpg < NS) { s += pv[k].x; q += pv[k].y; }
         for (int o = lpg >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
         if (l == 0) {
             float n = (float)HW * (float)(C / G);
@@ -81,29 +140,27 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
     }
     __syncthreads();
     const int cg = C / G;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        int gg = c / cg;
-        float sa = s_rstd[gg] * (float)gamma[c];
-        s_ab[c] = sa;
-        s_ab[C + c] = (float)beta[c] - s_mean[gg] * sa;
+#pragma unroll
+    for (int k = 0; k < GN_MAX_C / 256; ++k) {
+        int c = threadIdx.x + 256 * k;
+        if (c < C) {
+            int gg = c / cg;
+            float sa = s_rstd[gg] * gm[k];
+            s_ab[c] = sa;
+            s_ab[C + c] = bt[k] - s_mean[gg] * sa;
+        }
     }
     __syncthreads();
-    const int c8n = C / 8;
-    const f16 *xb = x + (size_t)b * HW * C;
-    f16 *yb = y + (size_t)b * HW * C;
-    const unsigned total = (unsigned)HW * (unsigned)c8n;
-    const unsigned stride = gridDim.x * 256u;
-    unsigned i = blockIdx.x * 256u + threadIdx.x;
-    unsigned c8 = i % (unsigned)c8n;
-    const unsigned cstep = stride % (unsigned)c8n;
-    for (; i < total; i += stride) {
-        int c0 = (int)c8 * 8;
-        f16x8 v = *(const f16x8 *)(xb + (size_t)i * 8);
+#pragma unroll
+    for (int u = 0; u < GN_AU; ++u) {
+        unsigned i = i0 + 256u * u;
+        if (i >= total) continue;
+        int c0 = (int)(i % (unsigned)c8n) * 8;
         f32x4 a0 = *(const f32x4 *)(s_ab + c0), a1 = *(const f32x4 *)(s_ab + c0 + 4);
         f32x4 b0 = *(const f32x4 *)(s_ab + C + c0), b1 = *(const f32x4 *)(s_ab + C + c0 + 4);
         float f[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { f[j] = (float)v[j] * a0[j] + b0[j]; f[4 + j] = (float)v[4 + j] * a1[j] + b1[j]; }
+        for (int j = 0; j < 4; ++j) { f[j] = (float)v[u][j] * a0[j] + b0[j]; f[4 + j] = (float)v[u][4 + j] * a1[j] + b1[j]; }
         f16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -112,13 +169,9 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
             o[j] = (f16)t;
         }
         *(f16x8 *)(yb + (size_t)i * 8) = o;
-        c8 += cstep;
-        if (c8 >= (unsigned)c8n) c8 -= (unsigned)c8n;
     }
 }
 
-#define GN_MAX_SPLITS 32
-#define GN_MAX_C 4096
 extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups)
 {
     return ((int64_t)B * GN_MAX_SPLITS * groups * 2 + (int64_t)B * 2 * GN_MAX_C) * 4;
@@ -133,15 +186,19 @@ extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const voi
                 "groupnorm: unsupported B=%d HW=%d C=%d groups=%d", B, HW, C, groups);
     hipStream_t s = (hipStream_t)stream;
     int c8n = C / 8;
-    int PL = c8n >= 256 ? 1024 / c8n : 256 / c8n;
+    int PL = 1024 / c8n;                                      // pixel lanes: ~1000 threads per block
     if (PL < 1) PL = 1;
+    if (PL > HW) PL = HW;
     int threads = c8n * PL;
-    int NS = min(GN_MAX_SPLITS, max(1, HW / (PL * 8)));
+    int NS = min(GN_MAX_SPLITS, max(1, HW / PL));             // >= one pixel per lane per split
     float *part = (float *)stats_ws;
-    size_t lds = (size_t)PL * C * 2 * sizeof(float);          // <= 64 KiB (threads <= 1024, 8 channels each)
-    hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), lds, s, (const f16 *)x, HW, C, groups, NS, part);
+    const int na = threads / C > 1 ? threads / C : 1;
+    size_t lds = (size_t)(PL + na) * C * 2 * sizeof(float);   // <= 72 KiB (threads <= 1024, 8 channels each)
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_gn_stats, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), lds, s, (const f16 *)x, HW, C, groups, NS, PL, part);
     size_t total = (size_t)HW * c8n;
-    int nb = (int)((total + 2047) / 2048 < 512 ? (total + 2047) / 2048 : 512);
+    int nb = (int)((total + 256 * GN_AU - 1) / (256 * GN_AU));
     hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, (const f16 *)x, part, (const f16 *)gamma,
                        (const f16 *)beta, HW, C, groups, NS, eps, silu, (f16 *)y);
     CTX_CHECK_LAUNCH("groupnorm");
@@ -149,47 +206,63 @@ extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const voi
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm over the last dim: one wave per row, up to 4 x 16-byte chunks per lane (C <= 2048).
+// LayerNorm over the last dim: one wave per LN_R rows at a time, up to 4 x 16-byte chunks per lane per row
+// (C <= 2048); all LN_R rows' loads are issued before the first reduction.
+template <int KC, int R>
 __global__ __launch_bounds__(256) void k_layernorm(const f16 *__restrict__ x, const f16 *__restrict__ gamma,
                                                    const f16 *__restrict__ beta, int64_t rows, int C, float eps,
                                                    f16 *__restrict__ y)
 {
     const int lane = threadIdx.x & 63;
     const int c8n = C / 8;
-    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; row < rows; row += ((int64_t)gridDim.x * 256) >> 6) {
-        const f16 *xr = x + row * C;
-        f16x8 v[4];
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t row0 = wave * R;
+    if (row0 >= rows) return;
+    f16x8 v[R][KC];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            int c8 = lane + 64 * k;
+            const int64_t rw = row0 + rr < rows ? row0 + rr : rows - 1;
+            v[rr][k] = *(const f16x8 *)(x + rw * C + min(c8, c8n - 1) * 8);          // unconditional load, masked below
+            if (c8 >= c8n) v[rr][k] = zero8;
+        }
+    f16x8 ga[KC], be[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        int c8 = lane + 64 * k;
+        ga[k] = *(const f16x8 *)(gamma + min(c8, c8n - 1) * 8);
+        be[k] = *(const f16x8 *)(beta + min(c8, c8n - 1) * 8);
+    }
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        if (row0 + rr >= rows) break;
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int c8 = lane + 64 * k;
-            if (c8 < c8n) {
-                v[k] = *(const f16x8 *)(xr + c8 * 8);
+        for (int k = 0; k < KC; ++k)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += (float)v[k][j];
-            }
-        }
-        float mean = wave_sum(s) / (float)C;
+            for (int j = 0; j < 8; ++j) s += (float)v[rr][k][j];            // padded lanes hold zeros
+        float mean = wave_sum_dpp(s) / (float)C;
         float q = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < KC; ++k) {
             int c8 = lane + 64 * k;
             if (c8 < c8n) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { float d = (float)v[k][j] - mean; q += d * d; }
+                for (int j = 0; j < 8; ++j) { float d = (float)v[rr][k][j] - mean; q += d * d; }
             }
         }
-        float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-        f16 *yr = y + row * C;
+        float rstd = rsqrtf(wave_sum_dpp(q) / (float)C + eps);
+        f16 *yr = y + (row0 + rr) * C;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < KC; ++k) {
             int c8 = lane + 64 * k;
             if (c8 < c8n) {
-                f16x8 ga = *(const f16x8 *)(gamma + c8 * 8);
-                f16x8 be = *(const f16x8 *)(beta + c8 * 8);
                 f16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)v[k][j] - mean) * rstd * (float)ga[j] + (float)be[j]);
+                for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)v[rr][k][j] - mean) * rstd * (float)ga[k][j] + (float)be[k][j]);
                 *(f16x8 *)(yr + c8 * 8) = o;
             }
         }
@@ -200,10 +273,17 @@ extern "C" int32_t ctx_layernorm_f16(const void *x, const void *gamma, const voi
                                      void *y, ctx_stream_t stream)
 {
     CTX_REQUIRE(x && gamma && beta && y && rows > 0 && C % 8 == 0 && C <= 2048, "layernorm: unsupported rows=%lld C=%d", (long long)rows, C);
-    int64_t nb = cdiv64(rows, 4);
-    if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const f16 *)x, (const f16 *)gamma,
-                       (const f16 *)beta, rows, C, eps, (f16 *)y);
+    const int kc = (C / 8 + 63) / 64;                          // 16-byte chunks per lane per row
+#define LN_GO(KC_, R_) do { int64_t nb = cdiv64(cdiv64(rows, R_), 4); \
+        hipLaunchKernelGGL((k_layernorm<KC_, R_>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const f16 *)x, \
+                           (const f16 *)gamma, (const f16 *)beta, rows, C, eps, (f16 *)y); } while (0)
+    // rows per wave: ~4 loads in flight per lane, but keep >= ~2 waves per SIMD of work on the chip
+    const bool many = rows >= 8192;
+    if (kc == 1) { if (many) LN_GO(1, 4); else LN_GO(1, 1); }
+    else if (kc == 2) { if (many) LN_GO(2, 2); else LN_GO(2, 1); }
+    else if (kc == 3) LN_GO(3, 1);
+    else LN_GO(4, 1);
+#undef LN_GO
     CTX_CHECK_LAUNCH("layernorm");
     return CTX_OK;
 }

@@ -33,6 +33,7 @@ struct ResP {
 struct TrP {
     int C, heads;
     size_t ng, nb, piw, pib, l1g, l1b, qkv, o1w, o1b, l2g, l2b, q2, kv2, o2w, o2b, l3g, l3b, f1w, f1b, f2w, f2b, pow_, pob;
+    int kv_row;     // first row of this block's [k ; v] slice in the fused cross-attention K/V projection
 };
 struct LevelP {
     std::vector<ResP> res;
@@ -49,6 +50,9 @@ struct ctx_unet {
     // parameter offsets
     size_t ciw, cib, t1w, t1b, t2w, t2b, tpw, tpb, cng, cnb, cow, cob;
     int temb_dim = 0, temb_rows = 0;
+    // all cross-attention to_k / to_v weights live in one [kv_rows_total, cross_dim] matrix (one GEMM per forward)
+    size_t kvw = 0;
+    int kv_rows_total = 0, kv_rows = 0;
     std::vector<LevelP> down, up;
     LevelP mid;
     // bound memory
@@ -122,7 +126,9 @@ static void add_transformer(ctx_unet *u, const std::string &p, int C, int heads,
     t.o1w = u->lin(b + ".attn1.to_out.0.weight", C, C); t.o1b = u->vec(b + ".attn1.to_out.0.bias", C);
     t.l2g = u->vec(b + ".norm2.weight", C); t.l2b = u->vec(b + ".norm2.bias", C);
     t.q2 = u->lin(b + ".attn2.to_q.weight", C, C);
-    t.kv2 = u->walloc((size_t)2 * C * cd);
+    t.kv_row = u->kv_rows;
+    t.kv2 = u->kvw + (size_t)u->kv_rows * cd;
+    u->kv_rows += 2 * C;
     u->add(b + ".attn2.to_k.weight", {C, cd}, PK_COPY, t.kv2);
     u->add(b + ".attn2.to_v.weight", {C, cd}, PK_COPY, t.kv2 + (size_t)C * cd);
     t.o2w = u->lin(b + ".attn2.to_out.0.weight", C, C); t.o2b = u->vec(b + ".attn2.to_out.0.bias", C);
@@ -158,6 +164,15 @@ extern "C" ctx_unet_t *ctx_unet_create(const ctx_unet_config_t *cfg)
     for (int i = 0; i < n; ++i) rows += (lpb + 1) * ch[n - 1 - i];
     u->tpw = u->walloc((size_t)rows * u->temb_dim);
     u->tpb = u->walloc(rows);
+    {
+        int kvr = 2 * ch[n - 1];                                        // mid block
+        for (int i = 0; i < n; ++i) {
+            if (cfg->down_attn[i]) kvr += lpb * 2 * ch[i];
+            if (cfg->up_attn[i]) kvr += (lpb + 1) * 2 * ch[n - 1 - i];
+        }
+        u->kv_rows_total = kvr;
+        u->kvw = u->walloc((size_t)kvr * cfg->cross_attention_dim);
+    }
 
     u->ciw = u->add("conv_in.weight", {ch[0], cfg->in_channels, 3, 3}, PK_CONVIN, u->walloc((size_t)ch[0] * 72), ch[0], cfg->in_channels);
     u->cib = u->vec("conv_in.bias", ch[0]);
@@ -216,6 +231,11 @@ extern "C" ctx_unet_t *ctx_unet_create(const ctx_unet_config_t *cfg)
     u->cng = u->vec("conv_norm_out.weight", ch[0]); u->cnb = u->vec("conv_norm_out.bias", ch[0]);
     u->cow = u->add("conv_out.weight", {cfg->out_channels, ch[0], 3, 3}, PK_CONV3, u->walloc((size_t)cfg->out_channels * ch[0] * 9), cfg->out_channels, ch[0]);
     u->cob = u->vec("conv_out.bias", cfg->out_channels);
+    if (u->kv_rows != u->kv_rows_total) {
+        ctx_set_error("unet_create: internal cross-attention K/V row count mismatch %d != %d", u->kv_rows, u->kv_rows_total);
+        delete u;
+        return nullptr;
+    }
     if (u->temb_rows != rows) {
         ctx_set_error("unet_create: internal temb row count mismatch %d != %d", u->temb_rows, rows);
         delete u;
@@ -354,6 +374,7 @@ struct FwdCtx {
     int B, L;
     const f16 *tproj;   // [B, temb_rows]
     const f16 *ctx16;   // [B*L, cd]
+    const f16 *kv_all;  // [B*L, kv_rows_total]: every block's cross-attention K | V projection of the context
     void *gn_stats;
 };
 
@@ -399,10 +420,9 @@ static f16 *run_transformer(ctx_unet *u, const FwdCtx &f, const TrP &t, const f1
     op_ln(u, h1, t.l2g, t.l2b, M, C, l);
     f16 *q = a;   // reuse
     op_gemm(u, l, t.q2, 0, false, nullptr, M, C, C, q);
-    f16 *kv = u->allocH((size_t)B * f.L * 2 * C);
-    op_gemm(u, f.ctx16, t.kv2, 0, false, nullptr, B * f.L, 2 * C, cd, kv);
+    const f16 *kv = f.kv_all + t.kv_row;
     f16 *a2 = u->allocH((size_t)M * C);
-    op_attn(u, q, kv, kv + C, B, S, f.L, t.heads, C, 2 * C, a2);
+    op_attn(u, q, kv, kv + C, B, S, f.L, t.heads, C, u->kv_rows_total, a2);
     f16 *h2 = h0;  // h0 is dead after h1 was produced
     op_gemm(u, a2, t.o2w, t.o2b, true, h1, M, C, C, h2);
     // feed forward (GEGLU fused into the first GEMM's epilogue)
@@ -438,6 +458,10 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
     f16 *ctx16 = u->allocH((size_t)B * L * c.cross_attention_dim);
     note(u, 2, 0); RUN(ctx_f32_to_f16(ctx, (int64_t)B * L * c.cross_attention_dim, ctx16, u->s));
     f.ctx16 = ctx16;
+    // cross-attention K/V of every transformer block in one GEMM: they depend only on the context
+    f16 *kv_all = u->allocH((size_t)B * L * u->kv_rows_total);
+    op_gemm(u, ctx16, u->kvw, 0, false, nullptr, B * L, u->kv_rows_total, c.cross_attention_dim, kv_all);
+    f.kv_all = kv_all;
 
     int h = H, w = W;
     f16 *x = u->allocH((size_t)B * h * w * ch[0]);

@@ -221,10 +221,12 @@ int32_t ctx_profile_begin(void);
 int32_t ctx_profile_end(int32_t klass, double *total_ms /*host*/, int64_t *count /*host*/);
 
 /* Benchmark support (tools/bench_gemm.py): `iters` back-to-back launches timed on the device; conv_B > 0 selects the
-   implicit-GEMM conv (N = Cout, input [conv_B, conv_H, conv_W, conv_Cin]).  Returns average ms per launch (< 0: error). */
+   implicit-GEMM conv (N = Cout, input [conv_B, conv_H, conv_W, conv_Cin]; conv_flags bit 0: stride 2, bit 1: fused nearest
+   x2 upsample).  epi 1: GEGLU epilogue.  splitk < 0: the UNet executor's own choice (needs `part`).  Returns average ms
+   per launch (< 0: error). */
 float ctx_bench_gemm(const void *A, const void *Wt, const void *bias, const void *residual, int32_t M, int32_t N, int32_t K,
-                     void *C, int32_t conv_B, int32_t conv_H, int32_t conv_W, int32_t conv_Cin, void *part, int32_t splitk,
-                     int32_t iters, ctx_stream_t stream);
+                     void *C, int32_t conv_B, int32_t conv_H, int32_t conv_W, int32_t conv_Cin, int32_t conv_flags, int32_t epi,
+                     void *part, int32_t splitk, int32_t iters, ctx_stream_t stream);
 
 /* Unit-test support: one 32x32 tile through the MFMA fragment maps the kernels assume.
    which 0: f16 32x32x16 (A[32][16], Bt[32][16]); 1: f32 32x32x2 (A[32][2], Bt[32][2]); C[32][32] f32. */

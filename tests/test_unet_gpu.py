@@ -72,6 +72,72 @@ def test_conv3x3(dev, B, H, W, Cin, Cout, stride, ups):
     _close(y.permute(0, 3, 1, 2), want, rtol=3e-3, atol=4e-3, what="conv3x3")
 
 
+@pytest.fixture
+def force_gemm8():
+    """Route every applicable GEMM / conv through the 256x256 8-wave kernel (gemm8.hip), whatever its size."""
+    import os
+    old = os.environ.get("CTX_GEMM8")
+    os.environ["CTX_GEMM8"] = "2"
+    yield
+    if old is None:
+        os.environ.pop("CTX_GEMM8", None)
+    else:
+        os.environ["CTX_GEMM8"] = old
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (300, 320, 320), (257, 72, 64), (1000, 2560, 128), (2048, 256, 1344)])
+def test_gemm8_forced(dev, force_gemm8, M, N, K):
+    test_gemm(dev, M, N, K)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [(2, 16, 16, 64, 64, 1, 0), (1, 9, 13, 128, 320, 1, 0),
+                                                        (2, 16, 12, 64, 128, 2, 0), (2, 8, 8, 128, 64, 1, 1),
+                                                        (2, 32, 32, 320, 320, 1, 0)])
+def test_conv8_forced(dev, force_gemm8, B, H, W, Cin, Cout, stride, ups):
+    test_conv3x3(dev, B, H, W, Cin, Cout, stride, ups)
+
+
+@pytest.mark.parametrize("forced", [0, 1])
+@pytest.mark.parametrize("M,C4,K,splitk", [(384, 256, 192, 1), (300, 96, 64, 1), (512, 0, 448, 3), (200, 0, 1024, 5)])
+def test_gemm_geglu_and_splitk(dev, M, C4, K, splitk, forced):
+    """GEGLU epilogue (packed [32 value | 32 gate] weight rows) and fp32 split-K slabs, through the benchmark entry."""
+    import os
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M + C4 + K)
+    old = os.environ.get("CTX_GEMM8")
+    os.environ["CTX_GEMM8"] = "2" if forced else "0"
+    try:
+        A = torch.randn(M, K, generator=g).half()
+        if C4:
+            Wv = (torch.randn(C4, K, generator=g) / K ** 0.5).half(); Wg = (torch.randn(C4, K, generator=g) / K ** 0.5).half()
+            bv = torch.randn(C4, generator=g).half(); bg = torch.randn(C4, generator=g).half()
+            Wp = torch.empty(2 * C4, K, dtype=torch.float16); bp = torch.empty(2 * C4, dtype=torch.float16)
+            for blk in range(C4 // 32):
+                Wp[64 * blk:64 * blk + 32] = Wv[32 * blk:32 * blk + 32]; Wp[64 * blk + 32:64 * blk + 64] = Wg[32 * blk:32 * blk + 32]
+                bp[64 * blk:64 * blk + 32] = bv[32 * blk:32 * blk + 32]; bp[64 * blk + 32:64 * blk + 64] = bg[32 * blk:32 * blk + 32]
+            out = torch.zeros(M, C4, dtype=torch.float16, device=dev)
+            Ad, Wd, bd = A.to(dev), Wp.to(dev), bp.to(dev)
+            ms = lib.ctx_bench_gemm(L.ptr(Ad), L.ptr(Wd), L.ptr(bd), None, M, 2 * C4, K, L.ptr(out), 0, 0, 0, 0, 0, 1, None, 1, 1, L.stream())
+            assert ms > 0, lib.ctx_last_error()
+            want = (A.float() @ Wv.float().T + bv.float()) * F.gelu(A.float() @ Wg.float().T + bg.float())
+            _close(out, want, rtol=3e-3, atol=3e-3, what="gemm+GEGLU")
+        else:
+            N = 320
+            W = (torch.randn(N, K, generator=g) / K ** 0.5).half(); bias = torch.randn(N, generator=g).half()
+            res = torch.randn(M, N, generator=g).half()
+            out = torch.zeros(M, N, dtype=torch.float16, device=dev)
+            part = torch.empty(splitk * M * N, dtype=torch.float32, device=dev)
+            Ad, Wd, bd, rd = A.to(dev), W.to(dev), bias.to(dev), res.to(dev)
+            ms = lib.ctx_bench_gemm(L.ptr(Ad), L.ptr(Wd), L.ptr(bd), L.ptr(rd), M, N, K, L.ptr(out), 0, 0, 0, 0, 0, 0, L.ptr(part), splitk, 1, L.stream())
+            assert ms > 0, lib.ctx_last_error()
+            _close(out, A.float() @ W.float().T + bias.float() + res.float(), what=f"gemm split-K {splitk}")
+    finally:
+        if old is None:
+            os.environ.pop("CTX_GEMM8", None)
+        else:
+            os.environ["CTX_GEMM8"] = old
+
+
 @pytest.mark.parametrize("B,HW,Cc,G,silu", [(2, 256, 64, 32, 1), (2, 1024, 320, 32, 1), (1, 144, 1280, 32, 0),
                                             (2, 400, 2560, 32, 1), (2, 576, 1920, 32, 1), (2, 100, 960, 32, 0)])
 def test_groupnorm(dev, B, HW, Cc, G, silu):
