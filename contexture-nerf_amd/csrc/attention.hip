@@ -166,7 +166,6 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a)
 // LDS-DMA variant (default): K and V^T tiles arrive by global_load_lds into a ring of AT_NS stages (1 KiB pieces of
 // 8 rows x 128 B, chunk swizzle c ^ ((row>>1)&7) on the source address and on the fragment reads), prefetch distance
 // AT_NS-1 tiles, one raw s_barrier + counted vmcnt per tile — the same pipeline as k_gemm_pipe.
-#define AT_NS 3
 __device__ __attribute__((aligned(16))) f16 g_attn_zero[64];
 typedef const __attribute__((address_space(1))) void *agptr_t;
 typedef __attribute__((address_space(3))) void *alptr_t;
@@ -242,6 +241,7 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
         }
 }
 
+template <int AT_NS>
 __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) f16 ring[AT_NS * 2 * 64 * 64];    // per stage: K [64][64] then V^T [64][64]
@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
             const int t = t0 + u;
             if (t < ntiles) {
                 int newer = issued - 1 - t;
-                if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+                if (AT_NS >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+                else if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (issued < ntiles) issue((u + AT_NS - 1) % AT_NS);
@@ -344,7 +345,9 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq,
     a.scale_log2e = scale * 1.4426950408889634f;
     static int impl = -1;
     if (impl < 0) { const char *e = getenv("CTX_ATTN_IMPL"); impl = e ? atoi(e) : 1; }
-    auto kern = impl == 1 ? k_attention_dma : k_attention;
+    static int ns = -1;
+    if (ns < 0) { const char *e = getenv("CTX_ATTN_NS"); ns = e ? atoi(e) : 3; }
+    auto kern = impl == 1 ? (ns == 2 ? k_attention_dma<2> : (ns == 4 ? k_attention_dma<4> : k_attention_dma<3>)) : k_attention;
     if (ctx_prof_on()) {
         hipEvent_t e0, e1;
         ctx_prof_events(1, &e0, &e1);

@@ -99,6 +99,55 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2
     }
 }
 
+// Epilogue through LDS: the accumulator layout gives every lane one token row and 4-feature pieces, i.e. 8-byte
+// accesses scattered over 32 cache lines per wave instruction, for the store AND for the residual read.  Each wave
+// instead parks 32 rows x 64 features of fp32 in its own LDS patch (row stride 68 floats: conflict-free ds_write_b128)
+// and walks it back 8 rows x 128 B per instruction: bias / row bias / residual / output all move as whole 128-byte
+// lines, 16 bytes per lane, and the sum is still rounded to fp16 exactly once.
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs &a, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int r,
+                                                     int h, float *stage, int lane)
+{
+    const int prow = lane >> 3, c8 = (lane & 7) * 8;
+    const int n = n0 + wn * 64 + c8;
+    f16x8 bs = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.bias && n < a.N) bs = *(const f16x8 *)(a.bias + n);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+                *(f32x4 *)(stage + r * 68 + ni * 32 + 8 * g + 4 * h) = v;
+            }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = 8 * p + prow;
+            const int m = m0 + wm * 64 + mi * 32 + row;
+            f32x4 v0 = *(const f32x4 *)(stage + row * 68 + c8), v1 = *(const f32x4 *)(stage + row * 68 + c8 + 4);
+            if (m < a.M && n < a.N) {
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)bs[j];
+                if (a.rowbias) {
+                    f16x8 b = *(const f16x8 *)(a.rowbias + (size_t)(m / a.rows_per_batch) * a.ldrb + n);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
+                }
+                if (a.residual) {
+                    f16x8 b = *(const f16x8 *)(a.residual + (size_t)m * a.ldr + n);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
+                }
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+                *(f16x8 *)(a.out + (size_t)m * a.ldc + n) = o;
+            }
+        }
+    }
+}
+
 template <int WM, int WN, bool CONV>
 __global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs a)
 {
@@ -514,6 +563,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
         }
         return;
     }
+    if (a.epi == 0 && a.stage_epi) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring
+        gemm_epilogue_staged(a, acc, m0, n0, wm, wn, r, h, (float *)smem + wave * (32 * 68), lane);
+        return;
+    }
     gemm_epilogue(a, acc, m0, n0, wm, wn, r, h);
 }
 
@@ -562,6 +617,9 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
         // unique operand bytes: weights N*K vs activations M*K (conv: M*Cin, the 9 taps re-read the same pixels)
         const double wbytes = (double)a.N * a.K, xbytes = (double)a.M * (CONV ? a.Cin : a.K);
         a.mfast = mfast >= 0 ? mfast : (wbytes > xbytes ? 1 : 0);
+        static int stg = -1;
+        if (stg < 0) { const char *e = getenv("CTX_GEMM_STAGE_EPI"); stg = e ? atoi(e) : 1; }
+        a.stage_epi = stg && (a.ldc % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0);
         static int pk64 = -1;
         if (pk64 < 0) { const char *e = getenv("CTX_GEMM_PK"); pk64 = (e && atoi(e) == 64) ? 1 : 0; }
         constexpr int NT = 64 * WM * WN;

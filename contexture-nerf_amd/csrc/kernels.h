@@ -21,6 +21,7 @@ struct GemmArgs {
     float *part;
     int pk;                // K-stage depth chosen by the launcher (32 or 64)
     int krot;              // 1: per-workgroup K rotation (spreads concurrent accesses to shared operand rows)
+    int stage_epi;         // 1: epilogue staged through LDS (whole-line stores / residual reads)
     int mfast;             // 1: consecutive workgroups walk M first (share the weight panel in their XCD's L2)
 };
 

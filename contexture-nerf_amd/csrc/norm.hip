@@ -100,35 +100,31 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
     const f16 *xb = x + (size_t)b * HW * C;
     f16 *yb = y + (size_t)b * HW * C;
     const unsigned total = (unsigned)HW * (unsigned)c8n;
-    const unsigned i0 = blockIdx.x * (256u * GN_AU) + threadIdx.x;
+    // a block owns a contiguous run of 16-byte chunks and walks it in batches of GN_AU x 256
+    const unsigned per = ((total + gridDim.x - 1) / gridDim.x + 255u) & ~255u;
+    const unsigned beg = blockIdx.x * per, end = min(total, beg + per);
     f16x8 v[GN_AU];
 #pragma unroll
-    for (int u = 0; u < GN_AU; ++u) {
-        unsigned i = min(i0 + 256u * u, total - 1u);                       // unconditional: no branch, no early wait
-        v[u] = *(const f16x8 *)(xb + (size_t)i * 8);                        // in flight during the fold below
-    }
-    // per-channel affine inputs and this lane's share of the split partials: every load issued before the first use
-    float gm[GN_MAX_C / 256], bt[GN_MAX_C / 256];
-#pragma unroll
-    for (int k = 0; k < GN_MAX_C / 256; ++k) {
-        int c = min((int)threadIdx.x + 256 * k, C - 1);
-        gm[k] = (float)gamma[c];
-        bt[k] = (float)beta[c];
+    for (int u = 0; u < GN_AU; ++u)                                         // first batch: in flight during the fold below
+        v[u] = *(const f16x8 *)(xb + (size_t)min(beg + 256u * u + threadIdx.x, total - 1u) * 8);
+    // gamma / beta go to LDS now (their latency overlaps the partial loads below instead of following the barrier)
+    for (int c = threadIdx.x; c < C; c += 256) {
+        s_ab[c] = (float)gamma[c];
+        s_ab[C + c] = (float)beta[c];
     }
     {
         const int lpg = 256 / G;
         const int g = threadIdx.x / lpg, l = threadIdx.x % lpg;
-        constexpr int MAXK = GN_MAX_SPLITS * GN_MAX_GROUPS / 256;          // partials per lane, worst case
-        float2 pv[MAXK];
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) {
-            int sp = min(l + k * lpg, NS - 1);
-            pv[k] = *(const float2 *)(part + (((size_t)b * NS + sp) * G + g) * 2);
-        }
         float s = 0.f, q = 0.f;
+        for (int k0 = 0; k0 < NS; k0 += 4 * lpg) {                          // 4 independent loads per trip, fixed order
+            float2 pv[4];
 #pragma unroll
-        for (int k = 0; k < MAXK; ++k)
-            if (l + k * lpg < NS) { s += pv[k].x; q += pv[k].y; }
+            for (int k = 0; k < 4; ++k)
+                pv[k] = *(const float2 *)(part + (((size_t)b * NS + min(k0 + k * lpg + l, NS - 1)) * G + g) * 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k0 + k * lpg + l < NS) { s += pv[k].x; q += pv[k].y; }
+        }
         for (int o = lpg >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
         if (l == 0) {
             float n = (float)HW * (float)(C / G);
@@ -140,35 +136,44 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
     }
     __syncthreads();
     const int cg = C / G;
-#pragma unroll
-    for (int k = 0; k < GN_MAX_C / 256; ++k) {
-        int c = threadIdx.x + 256 * k;
-        if (c < C) {
-            int gg = c / cg;
-            float sa = s_rstd[gg] * gm[k];
-            s_ab[c] = sa;
-            s_ab[C + c] = bt[k] - s_mean[gg] * sa;
-        }
+    for (int c = threadIdx.x; c < C; c += 256) {                             // same thread wrote these two cells above
+        int gg = c / cg;
+        float sa = s_rstd[gg] * s_ab[c];
+        s_ab[C + c] = s_ab[C + c] - s_mean[gg] * sa;
+        s_ab[c] = sa;
     }
     __syncthreads();
+    for (unsigned i0 = beg; i0 < end; i0 += 256u * GN_AU) {
+        f16x8 nx[GN_AU];
+        const unsigned n0 = i0 + 256u * GN_AU;
+        if (n0 < end) {
 #pragma unroll
-    for (int u = 0; u < GN_AU; ++u) {
-        unsigned i = i0 + 256u * u;
-        if (i >= total) continue;
-        int c0 = (int)(i % (unsigned)c8n) * 8;
-        f32x4 a0 = *(const f32x4 *)(s_ab + c0), a1 = *(const f32x4 *)(s_ab + c0 + 4);
-        f32x4 b0 = *(const f32x4 *)(s_ab + C + c0), b1 = *(const f32x4 *)(s_ab + C + c0 + 4);
-        float f[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { f[j] = (float)v[u][j] * a0[j] + b0[j]; f[4 + j] = (float)v[u][4 + j] * a1[j] + b1[j]; }
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float t = f[j];
-            if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
-            o[j] = (f16)t;
+            for (int u = 0; u < GN_AU; ++u) nx[u] = *(const f16x8 *)(xb + (size_t)min(n0 + 256u * u + threadIdx.x, total - 1u) * 8);
         }
-        *(f16x8 *)(yb + (size_t)i * 8) = o;
+#pragma unroll
+        for (int u = 0; u < GN_AU; ++u) {
+            const unsigned i = i0 + 256u * u + threadIdx.x;
+            if (i < end) {
+                int c0 = (int)(i % (unsigned)c8n) * 8;
+                f32x4 a0 = *(const f32x4 *)(s_ab + c0), a1 = *(const f32x4 *)(s_ab + c0 + 4);
+                f32x4 b0 = *(const f32x4 *)(s_ab + C + c0), b1 = *(const f32x4 *)(s_ab + C + c0 + 4);
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = (float)v[u][j] * a0[j] + b0[j]; f[4 + j] = (float)v[u][4 + j] * a1[j] + b1[j]; }
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = f[j];
+                    if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+                    o[j] = (f16)t;
+                }
+                *(f16x8 *)(yb + (size_t)i * 8) = o;
+            }
+        }
+        if (n0 < end) {
+#pragma unroll
+            for (int u = 0; u < GN_AU; ++u) v[u] = nx[u];
+        }
     }
 }
 
@@ -198,7 +203,10 @@ extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const voi
     if (!attr) { (void)hipFuncSetAttribute((const void *)k_gn_stats, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }
     hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), lds, s, (const f16 *)x, HW, C, groups, NS, PL, part);
     size_t total = (size_t)HW * c8n;
+    // fat blocks (the per-block fold of the split partials is amortised): ~2 per CU, at least one batch each
     int nb = (int)((total + 256 * GN_AU - 1) / (256 * GN_AU));
+    const int cap = B >= 2 ? 256 : 512;
+    if (nb > cap) nb = cap;
     hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, (const f16 *)x, part, (const f16 *)gamma,
                        (const f16 *)beta, HW, C, groups, NS, eps, silu, (f16 *)y);
     CTX_CHECK_LAUNCH("groupnorm");
