@@ -69,6 +69,7 @@ SIGNATURES = {
     "ctx_profile_begin": (_i32, []),
     "ctx_profile_end": (_i32, [_i32, _vp, _vp]),
     "ctx_bench_gemm": (C.c_float, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "ctx_gemm_tune": (None, [_i32, _i32]),
     "ctx_probe_mfma": (_i32, [_i32, _vp, _vp, _vp, _vp]),
     "ctx_cfg_plms_step": (_i32, [_vp, _i64, _f32, _vp, _i32, _vp, _f32, _f32, _i32, _vp, _vp, _vp]),
 }

@@ -1,28 +1,23 @@
-// fp16 MFMA GEMM / implicit-GEMM 3x3 convolution for the UNet denoiser (gfx950).
+// fp16 MFMA GEMM / implicit-GEMM 3x3 convolution for the UNet denoiser (gfx950), small and medium tiles.
 //
 //   out[M,N] = X[M,K] . Wt[N,K]^T  (+bias[N]) (+rowbias[row/rows_per_batch, N]) (+residual[M,N])
 //
 // Replaces the cuDNN/cuBLAS conv2d / linear calls under diffusers' UNet2DConditionModel
 // (reference call site src/stable_diffusion_depth.py:422-423).  fp16 operands, fp32 accumulate.
 //
-// Structure: 256 threads = 4 waves, each wave owns a 64(m) x 64(n) sub-tile as 2x2 accumulators of
-// v_mfma_f32_32x32x16_f16.  The WEIGHT fragment is the A operand and the ACTIVATION fragment the B
-// operand, so a lane owns one output row (token / pixel) and its registers walk the features: the
-// epilogue packs 4 consecutive features into one 8-byte store and bias / GEGLU are register-local.
-// Tiles: <2,2> = 128x128, <4,1> = 256(m) x 64(n) (for N = 320 = 5 x 64, no masked columns).
-// K-tiles of 64 are register-staged (global -> VGPR -> padded LDS rows of 144 B: conflict-free
-// ds_read_b128) with the next tile's loads issued before the current tile's MFMAs; one barrier per tile.
-// The conv variant only changes the activation-tile address generator (im2col on the fly, NHWC,
-// zero padding by predication, optional fused nearest x2 upsample and stride 2).
+// One kernel template, k_gemm_pipe<WM, WN, MI, NI, CONV, NS, PKT>: WM x WN waves, each owning MI x NI accumulators of
+// v_mfma_f32_32x32x16_f16.  The WEIGHT fragment is the A operand and the ACTIVATION fragment the B operand, so a lane
+// owns one output row (token / pixel) and its registers walk the features.  Operand tiles go global -> LDS by
+// global_load_lds_dwordx4 into a ring of NS K-stages (PKT deep), one raw s_barrier per stage and a counted vmcnt so the
+// newer stages stay in flight.  What limits these layers is how many bytes per clock a CU can stage (about 1 KiB per
+// ~120 cycles per issuing wave, ~30 B/clk per CU), not the matrix pipe: the tile list below trades flop per staged
+// byte (big tiles) against waves that issue (small problems want 4-8 waves even on a 64x64 tile).  The conv variant
+// only changes the activation address generator (im2col on the fly, NHWC, zero padding by pointing at a zero page,
+// optional fused nearest x2 upsample and stride 2).  The large layers go to gemm8.hip (256x256, 8 staggered waves).
 #include "common.h"
 #include "kernels.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
-
-#define GK 64          // K-tile
-#define LDS_ROW 72     // f16 per LDS row (64 + 8 pad) = 144 B
-
-
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 {
@@ -41,36 +36,39 @@ __device__ __forceinline__ float fast_erf(float x)
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int r, int h)
+// Direct epilogue (GEGLU, or when strides are not 16-byte friendly): lane owns row m, registers walk n.
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[MI][NI], int mw, int nw, int r, int h)
 {
-    // ---- epilogue: lane owns row m, registers walk n ---------------------------------------------
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        int m = m0 + wm * 64 + mi * 32 + r;
+    for (int mi = 0; mi < MI; ++mi) {
+        int m = mw + mi * 32 + r;
         if (m >= a.M) continue;
         int bidx = a.rowbias ? m / a.rows_per_batch : 0;
         if (a.epi == 1) {
-            // GEGLU: ni=0 -> value half, ni=1 -> gate half of the same 32 features (packed weight order)
-            int fbase = (n0 + wn * 64) / 2;
+            if constexpr (NI == 2) {
+                // GEGLU: ni=0 -> value half, ni=1 -> gate half of the same 32 features (packed weight order)
+                int fbase = nw / 2;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int nn = n0 + wn * 64 + 8 * g + 4 * h;       // packed column of the value half
-                if (nn >= a.N) continue;
-                f16x4 o;
+                for (int g = 0; g < 4; ++g) {
+                    int nn = nw + 8 * g + 4 * h;       // packed column of the value half
+                    if (nn >= a.N) continue;
+                    f16x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float xv = acc[mi][0][4 * g + j], gv = acc[mi][1][4 * g + j];
-                    if (a.bias) { xv += (float)a.bias[nn + j]; gv += (float)a.bias[nn + 32 + j]; }
-                    o[j] = (f16)(xv * gelu_erf(gv));
+                    for (int j = 0; j < 4; ++j) {
+                        float xv = acc[mi][0][4 * g + j], gv = acc[mi][1][4 * g + j];
+                        if (a.bias) { xv += (float)a.bias[nn + j]; gv += (float)a.bias[nn + 32 + j]; }
+                        o[j] = (f16)(xv * gelu_erf(gv));
+                    }
+                    *(f16x4 *)(a.out + (size_t)m * a.ldc + fbase + 8 * g + 4 * h) = o;
                 }
-                *(f16x4 *)(a.out + (size_t)m * a.ldc + fbase + 8 * g + 4 * h) = o;
             }
         } else {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    int nn = n0 + wn * 64 + ni * 32 + 8 * g + 4 * h;
+                    int nn = nw + ni * 32 + 8 * g + 4 * h;
                     if (nn >= a.N) continue;
                     float v[4];
 #pragma unroll
@@ -101,30 +99,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2
 
 // Epilogue through LDS: the accumulator layout gives every lane one token row and 4-feature pieces, i.e. 8-byte
 // accesses scattered over 32 cache lines per wave instruction, for the store AND for the residual read.  Each wave
-// instead parks 32 rows x 64 features of fp32 in its own LDS patch (row stride 68 floats: conflict-free ds_write_b128)
-// and walks it back 8 rows x 128 B per instruction: bias / row bias / residual / output all move as whole 128-byte
-// lines, 16 bytes per lane, and the sum is still rounded to fp16 exactly once.
-__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs &a, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int r,
-                                                     int h, float *stage, int lane)
+// instead parks 32 rows x (32 NI) features of fp32 in its own LDS patch (row stride 32 NI + 4 floats: conflict-free
+// ds_write_b128) and walks it back in whole rows: bias / row bias / residual / output all move as 64- or 128-byte
+// row segments, 16 bytes per lane, and the sum is still rounded to fp16 exactly once.
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs &a, f32x16 (&acc)[MI][NI], int mw, int nw, int r, int h,
+                                                     float *stage, int lane)
 {
-    const int prow = lane >> 3, c8 = (lane & 7) * 8;
-    const int n = n0 + wn * 64 + c8;
+    constexpr int RS = 32 * NI + 4;                    // patch row stride (floats)
+    constexpr int LPR = 4 * NI;                        // lanes per row (8 features each)
+    constexpr int RPP = 64 / LPR;                      // rows per pass
+    const int prow = lane / LPR, c8 = (lane % LPR) * 8;
+    const int n = nw + c8;
     f16x8 bs = {0, 0, 0, 0, 0, 0, 0, 0};
     if (a.bias && n < a.N) bs = *(const f16x8 *)(a.bias + n);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-                *(f32x4 *)(stage + r * 68 + ni * 32 + 8 * g + 4 * h) = v;
+                *(f32x4 *)(stage + r * RS + ni * 32 + 8 * g + 4 * h) = v;
             }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = 8 * p + prow;
-            const int m = m0 + wm * 64 + mi * 32 + row;
-            f32x4 v0 = *(const f32x4 *)(stage + row * 68 + c8), v1 = *(const f32x4 *)(stage + row * 68 + c8 + 4);
+        for (int p = 0; p < 32 / RPP; ++p) {
+            const int row = RPP * p + prow;
+            const int m = mw + mi * 32 + row;
+            f32x4 v0 = *(const f32x4 *)(stage + row * RS + c8), v1 = *(const f32x4 *)(stage + row * RS + c8 + 4);
             if (m < a.M && n < a.N) {
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
@@ -148,230 +150,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs &a, f32x16 (
     }
 }
 
-template <int WM, int WN, bool CONV>
-__global__ __launch_bounds__(256) void k_gemm_f16(GemmArgs a)
-{
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int XP = BM / 32, WP = BN / 32;      // staging passes (16-byte chunks per thread)
-    extern __shared__ __attribute__((aligned(16))) f16 smem[];
-    f16 *Xs = smem;                                 // [2][BM][LDS_ROW]
-    f16 *Ws = smem + 2 * BM * LDS_ROW;              // [2][BN][LDS_ROW]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int bid = xcd_remap(blockIdx.x, a.ntm * a.ntn);
-    const int tile_n = bid % a.ntn, tile_m = bid / a.ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int srow = tid >> 3, kc = tid & 7;        // staging: row within a 32-row pass, 16-B chunk
-
-    // ---- per-thread source bookkeeping for the activation tile -------------------------------
-    int xoff[XP];          // element offset of (row, k=0) [gemm] or of (b, 0, 0, 0) pixel base [conv]
-    int xoy[XP], xox[XP];
-    bool xok[XP];
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-        int m = m0 + srow + 32 * i;
-        xok[i] = m < a.M;
-        if (CONV) {
-            int hw = a.Ho * a.Wo;
-            int b = m / hw, p = m - b * hw;
-            int oy = p / a.Wo, ox = p - oy * a.Wo;
-            xoy[i] = oy * a.stride; xox[i] = ox * a.stride;
-            xoff[i] = b * a.H * a.W * a.Cin;
-        } else {
-            xoff[i] = m * a.K; xoy[i] = 0; xox[i] = 0;
-        }
-    }
-    int woff[WP];
-    bool wok[WP];
-#pragma unroll
-    for (int i = 0; i < WP; ++i) {
-        int n = n0 + srow + 32 * i;
-        wok[i] = n < a.N;
-        woff[i] = n * a.K;
-    }
-
-    f16x8 xs[XP], ws[WP];
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto load_tile = [&](int kt) {
-        int k0 = kt * GK + kc * 8;
-        if (CONV) {
-            int kk = kt * GK;
-            int tap = kk / a.Cin, c0 = kk - tap * a.Cin + kc * 8;
-            int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            int Hv = a.H << a.ups, Wv = a.W << a.ups;
-#pragma unroll
-            for (int i = 0; i < XP; ++i) {
-                int iy = xoy[i] + dy, ix = xox[i] + dx;
-                bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-                int off = xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0;
-                xs[i] = ok ? *(const f16x8 *)(a.X + off) : zero8;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < XP; ++i) xs[i] = xok[i] ? *(const f16x8 *)(a.X + xoff[i] + k0) : zero8;
-        }
-#pragma unroll
-        for (int i = 0; i < WP; ++i) ws[i] = wok[i] ? *(const f16x8 *)(a.Wt + woff[i] + k0) : zero8;
-    };
-    auto store_tile = [&](int buf) {
-        f16 *xd = Xs + buf * BM * LDS_ROW + srow * LDS_ROW + kc * 8;
-        f16 *wd = Ws + buf * BN * LDS_ROW + srow * LDS_ROW + kc * 8;
-#pragma unroll
-        for (int i = 0; i < XP; ++i) *(f16x8 *)(xd + 32 * i * LDS_ROW) = xs[i];
-#pragma unroll
-        for (int i = 0; i < WP; ++i) *(f16x8 *)(wd + 32 * i * LDS_ROW) = ws[i];
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-
-    const int nk = a.K / GK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const f16 *xb = Xs + buf * BM * LDS_ROW + (wm * 64 + r) * LDS_ROW + 8 * h;
-        const f16 *wb = Ws + buf * BN * LDS_ROW + (wn * 64 + r) * LDS_ROW + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < GK / 16; ++ks) {
-            f16x8 xf0 = *(const f16x8 *)(xb + ks * 16);
-            f16x8 xf1 = *(const f16x8 *)(xb + 32 * LDS_ROW + ks * 16);
-            f16x8 wf0 = *(const f16x8 *)(wb + ks * 16);
-            f16x8 wf1 = *(const f16x8 *)(wb + 32 * LDS_ROW + ks * 16);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf0, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf1, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf1, acc[1][1], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-
-    gemm_epilogue(a, acc, m0, n0, wm, wn, r, h);
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// LDS-DMA variant (default): tiles go global -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave
-// instruction, no staging VGPRs), single LDS buffer, two barriers per K-tile.  LDS use is 32-40 KiB and the
-// register budget ~110, so 3-4 workgroups share a CU and overlap each other's load / MFMA phases.
-// The LDS image is lane-linear ([rows][128 B]); bank conflicts are avoided by XOR-swizzling the 16-byte chunk
-// index with (row>>1)&7 on the per-lane SOURCE address and again on the fragment read.
-// Padding / out-of-range rows read from a zero page.
 __device__ __attribute__((aligned(16))) f16 g_zero_page[64];
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
-
-template <int WM, int WN, bool CONV>
-__global__ __launch_bounds__(256) void k_gemm_glds(GemmArgs a)
-{
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int XI = BM / 32, WI = BN / 32;      // LDS-DMA instructions per wave per K-tile
-    extern __shared__ __attribute__((aligned(16))) f16 smem[];
-    f16 *Xs = smem;                                 // [BM][64]
-    f16 *Ws = smem + BM * 64;                       // [BN][64]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int bid = xcd_remap(blockIdx.x, a.ntm * a.ntn);
-    const int tile_n = bid % a.ntn, tile_m = bid / a.ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int lr = lane >> 3, pc = lane & 7;        // row within the instruction's 8 rows, physical chunk
-
-    int xoff[XI], xoy[XI], xox[XI], xlc[XI];
-    bool xok[XI];
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        int row = 8 * (wave + 4 * i) + lr;
-        int m = m0 + row;
-        xlc[i] = (pc ^ ((row >> 1) & 7)) * 8;       // logical chunk (in f16) this lane must fetch
-        xok[i] = m < a.M;
-        if (CONV) {
-            int hw = a.Ho * a.Wo;
-            int b = m / hw, p = m - b * hw;
-            int oy = p / a.Wo, ox = p - oy * a.Wo;
-            xoy[i] = oy * a.stride; xox[i] = ox * a.stride;
-            xoff[i] = b * a.H * a.W * a.Cin;
-        } else {
-            xoff[i] = m * a.K; xoy[i] = 0; xox[i] = 0;
-        }
-    }
-    int woff[WI], wlc[WI];
-    bool wok[WI];
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-        int row = 8 * (wave + 4 * i) + lr;
-        wlc[i] = (pc ^ ((row >> 1) & 7)) * 8;
-        wok[i] = (n0 + row) < a.N;
-        woff[i] = (n0 + row) * a.K;
-    }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-
-    const int swz = (r >> 1) & 7;
-    const f16 *xb = Xs + (wm * 64 + r) * 64;
-    const f16 *wb = Ws + (wn * 64 + r) * 64;
-    const int nk = a.K / GK;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int k0 = kt * GK;
-        if (CONV) {
-            int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
-            int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            int Hv = a.H << a.ups, Wv = a.W << a.ups;
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                int iy = xoy[i] + dy, ix = xox[i] + dx;
-                bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-                const f16 *src = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 + xlc[i] : g_zero_page;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (wave + 4 * i) * 512), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const f16 *src = xok[i] ? a.X + xoff[i] + k0 + xlc[i] : g_zero_page;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (wave + 4 * i) * 512), 16, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const f16 *src = wok[i] ? a.Wt + woff[i] + k0 + wlc[i] : g_zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ws + (wave + 4 * i) * 512), 16, 0, 0);
-        }
-        __syncthreads();                            // vmcnt(0) + barrier: the tile has landed
-#pragma unroll
-        for (int ks = 0; ks < GK / 16; ++ks) {
-            const int pch = ((2 * ks + h) ^ swz) * 8;
-            f16x8 xf0 = *(const f16x8 *)(xb + pch);
-            f16x8 xf1 = *(const f16x8 *)(xb + 32 * 64 + pch);
-            f16x8 wf0 = *(const f16x8 *)(wb + pch);
-            f16x8 wf1 = *(const f16x8 *)(wb + 32 * 64 + pch);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf0, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf1, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf1, acc[1][1], 0, 0, 0);
-        }
-        __syncthreads();                            // everyone is done reading before the next tile overwrites
-    }
-    gemm_epilogue(a, acc, m0, n0, wm, wn, r, h);
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Pipelined LDS-DMA variant: K-stages of 32, ring of NS stages, prefetch distance NS-1, ONE raw s_barrier per
@@ -382,11 +164,10 @@ __global__ __launch_bounds__(256) void k_gemm_glds(GemmArgs a)
 //                  8 x MFMA on stage kt
 // 64-byte LDS rows ([rows][32 f16]), chunk swizzle c ^ ((row>>2)&3) applied on the DMA source address and on the
 // fragment read (conflict-free ds_read_b128 under the 64-bank / 16-lane-group rule).
-#define PK 32
-template <int WM, int WN, bool CONV, int NS, int PKT>
+template <int WM, int WN, int MI, int NI, bool CONV, int NS, int PKT>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
 {
-    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NW = WM * WN;
     constexpr int RP = 512 / PKT;                   // rows per 1-KiB DMA piece (16 x 64 B or 8 x 128 B)
     constexpr int LPR = PKT / 8;                    // lanes (16-B chunks) per row
     constexpr int XI = BM / (RP * NW), WI = BN / (RP * NW);   // DMA pieces per wave per stage
@@ -501,11 +282,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
         ++issued;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
@@ -513,7 +294,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
     for (int p = 0; p < NS - 1; ++p)
         if (p < nk) issue(p);
     const int swz = PKT == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7);
-    const int xrow = (wm * 64 + r) * PKT, wrow = BM * PKT + (wn * 64 + r) * PKT;
+    const int xrow = (wm * 32 * MI + r) * PKT, wrow = BM * PKT + (wn * 32 * NI + r) * PKT;
     for (int kt = 0; kt < nk; kt += NS) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
@@ -533,14 +314,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
 #pragma unroll
                 for (int ks = 0; ks < PKT / 16; ++ks) {
                     const int pch = ((2 * ks + h) ^ swz) * 8;
-                    f16x8 xf0 = *(const f16x8 *)(sb + xrow + pch);
-                    f16x8 xf1 = *(const f16x8 *)(sb + xrow + 32 * PKT + pch);
-                    f16x8 wf0 = *(const f16x8 *)(sb + wrow + pch);
-                    f16x8 wf1 = *(const f16x8 *)(sb + wrow + 32 * PKT + pch);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf0, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0, xf1, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1, xf1, acc[1][1], 0, 0, 0);
+                    f16x8 xf[MI], wf[NI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8 *)(sb + xrow + i * 32 * PKT + pch);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) wf[j] = *(const f16x8 *)(sb + wrow + j * 32 * PKT + pch);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -548,14 +330,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
     if (a.splitk > 1) {
         float *pb = a.part + (size_t)slice * a.M * a.N;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            int m = m0 + wm * 64 + mi * 32 + r;
+        for (int mi = 0; mi < MI; ++mi) {
+            int m = m0 + wm * 32 * MI + mi * 32 + r;
             if (m >= a.M) continue;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    int nn = n0 + wn * 64 + ni * 32 + 8 * g + 4 * h;
+                    int nn = n0 + wn * 32 * NI + ni * 32 + 8 * g + 4 * h;
                     if (nn >= a.N) continue;
                     f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
                     *(f32x4 *)(pb + (size_t)m * a.N + nn) = v;
@@ -566,10 +348,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
     if (a.epi == 0 && a.stage_epi) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring
-        gemm_epilogue_staged(a, acc, m0, n0, wm, wn, r, h, (float *)smem + wave * (32 * 68), lane);
+        gemm_epilogue_staged<MI, NI>(a, acc, m0 + wm * 32 * MI, n0 + wn * 32 * NI, r, h, (float *)smem + wave * (32 * (32 * NI + 4)), lane);
         return;
     }
-    gemm_epilogue(a, acc, m0, n0, wm, wn, r, h);
+    gemm_epilogue<MI, NI>(a, acc, m0 + wm * 32 * MI, n0 + wn * 32 * NI, r, h);
 }
 
 // Split-K second pass: out = sum_s part[s] (+bias)(+rowbias)(+residual) -> f16.  Fixed summation order.
@@ -596,97 +378,60 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a)
     }
 }
 
-static int gemm_impl()
+// tile ids (CTX_GEMM_TILE / ctx_gemm_tune): WM x WN waves of MI x NI 32x32 blocks
+//   0: 256x128 8w   1: 128x128 4w   2: 256x64 4w   3: 128x64 2w   4: 64x64 1w
+//   5: 64x64 4w (32x32 per wave)   6: 64x64 2w (64x32)   7: 128x128 8w (32x64)   8: 64x128 4w (32x64)   9: 128x64 4w (64x32)
+static int g_force_tile = -1, g_force_gemm8 = -1;
+extern "C" void ctx_gemm_tune(int32_t tile, int32_t gemm8)
 {
-    static int impl = -1;
-    if (impl < 0) { const char *e = getenv("CTX_GEMM_IMPL"); impl = e ? atoi(e) : 2; }
-    return impl;
+    g_force_tile = tile;            // -1: heuristic
+    g_force_gemm8 = gemm8;          // -1: heuristic, 0: never, 1: always when applicable
 }
 
-template <int WM, int WN, bool CONV>
+template <int WM, int WN, int MI, int NI, bool CONV>
 static void launch_gemm(GemmArgs &a, hipStream_t s)
 {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
     a.ntm = cdiv(a.M, BM);
     a.ntn = cdiv(a.N, BN);
-    const int impl = gemm_impl();
-    if (a.splitk < 1 || !a.part || impl != 2) a.splitk = 1;
-    if (impl == 2) {
-        static int mfast = -2;
-        if (mfast == -2) { const char *e = getenv("CTX_GEMM_MFAST"); mfast = e ? atoi(e) : -1; }
-        // unique operand bytes: weights N*K vs activations M*K (conv: M*Cin, the 9 taps re-read the same pixels)
-        const double wbytes = (double)a.N * a.K, xbytes = (double)a.M * (CONV ? a.Cin : a.K);
-        a.mfast = mfast >= 0 ? mfast : (wbytes > xbytes ? 1 : 0);
-        static int stg = -1;
-        if (stg < 0) { const char *e = getenv("CTX_GEMM_STAGE_EPI"); stg = e ? atoi(e) : 1; }
-        a.stage_epi = stg && (a.ldc % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0);
-        static int pk64 = -1;
-        if (pk64 < 0) { const char *e = getenv("CTX_GEMM_PK"); pk64 = (e && atoi(e) == 64) ? 1 : 0; }
-        constexpr int NT = 64 * WM * WN;
-        auto go = [&](auto kern, size_t lds, bool &attr_done) {
-            if (!attr_done) {
-                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_done = true;
-            }
-            if (ctx_prof_on()) {
-                hipEvent_t e0, e1;
-                ctx_prof_events(0, &e0, &e1);
-                hipExtLaunchKernelGGL(kern, dim3(a.ntm * a.ntn * a.splitk), dim3(NT), lds, s, e0, e1, 0, a);
-            } else
-                hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn * a.splitk), dim3(NT), lds, s, a);
-        };
-        if (pk64 && a.K % 64 == 0 && (!CONV || a.Cin % 64 == 0)) {
-            a.pk = 64;
-            static bool d64 = false;
-            go(k_gemm_pipe<WM, WN, CONV, 3, 64>, (size_t)3 * (BM + BN) * 64 * sizeof(f16), d64);
-        } else {
-            a.pk = 32;
-            static int krot = -1;
-            if (krot < 0) { const char *e = getenv("CTX_GEMM_KROT"); krot = e ? atoi(e) : 0; }
-            a.krot = krot;
-            static bool d32 = false;
-            // deeper rings for the small tiles: a 1- or 2-wave workgroup needs more bytes in flight to pull its share
-            constexpr int NSD = (WM * WN == 1) ? 8 : (WM * WN == 2 ? 6 : 4);
-            static int deep = -1;
-            if (deep < 0) { const char *e = getenv("CTX_GEMM_DEEP"); deep = e ? atoi(e) : 0; }
-            static bool d32b = false;
-            if (deep && NSD != 4) go(k_gemm_pipe<WM, WN, CONV, NSD, 32>, (size_t)NSD * (BM + BN) * 32 * sizeof(f16), d32b);
-            else go(k_gemm_pipe<WM, WN, CONV, 4, 32>, (size_t)4 * (BM + BN) * 32 * sizeof(f16), d32);
-        }
-        if (a.splitk > 1) {
-            size_t total = (size_t)a.M * (a.N / 4);
-            unsigned nb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-            if (ctx_prof_on()) {
-                hipEvent_t e0, e1;
-                ctx_prof_events(0, &e0, &e1);
-                hipExtLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, e0, e1, 0, a);
-            } else
-                hipLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, a);
-        }
-        return;
-    }
-    if (impl == 1) {
-        size_t lds = (size_t)(BM + BN) * 64 * sizeof(f16);
-        if (ctx_prof_on()) {
-            hipEvent_t e0, e1;
-            ctx_prof_events(0, &e0, &e1);
-            hipExtLaunchKernelGGL((k_gemm_glds<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, e0, e1, 0, a);
-        } else
-            hipLaunchKernelGGL((k_gemm_glds<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, a);
-        return;
-    }
-    size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(f16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_gemm_f16<WM, WN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    if (a.splitk < 1 || !a.part) a.splitk = 1;
+    static int mfast = -2;
+    if (mfast == -2) { const char *e = getenv("CTX_GEMM_MFAST"); mfast = e ? atoi(e) : -1; }
+    // unique operand bytes: weights N*K vs activations M*K (conv: M*Cin, the 9 taps re-read the same pixels)
+    const double wbytes = (double)a.N * a.K, xbytes = (double)a.M * (CONV ? a.Cin : a.K);
+    a.mfast = mfast >= 0 ? mfast : (wbytes > xbytes ? 1 : 0);
+    static int stg = -1;
+    if (stg < 0) { const char *e = getenv("CTX_GEMM_STAGE_EPI"); stg = e ? atoi(e) : 1; }
+    a.stage_epi = stg && (a.ldc % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0);
+    a.pk = 32; a.krot = 0;
+    constexpr int NT = 64 * WM * WN;
+    constexpr size_t ring = (size_t)4 * (BM + BN) * 32 * sizeof(f16);
+    constexpr size_t patch = (size_t)WM * WN * 32 * (32 * NI + 4) * sizeof(float);
+    constexpr size_t lds = ring > patch ? ring : patch;
+    auto kern = k_gemm_pipe<WM, WN, MI, NI, CONV, 4, 32>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
     }
     if (ctx_prof_on()) {
         hipEvent_t e0, e1;
         ctx_prof_events(0, &e0, &e1);
-        hipExtLaunchKernelGGL((k_gemm_f16<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, e0, e1, 0, a);
+        hipExtLaunchKernelGGL(kern, dim3(a.ntm * a.ntn * a.splitk), dim3(NT), lds, s, e0, e1, 0, a);
     } else
-        hipLaunchKernelGGL((k_gemm_f16<WM, WN, CONV>), dim3(a.ntm * a.ntn), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn * a.splitk), dim3(NT), lds, s, a);
+}
+
+static void launch_reduce(GemmArgs &a, hipStream_t s)
+{
+    size_t total = (size_t)a.M * (a.N / 4);
+    unsigned nb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (ctx_prof_on()) {
+        hipEvent_t e0, e1;
+        ctx_prof_events(0, &e0, &e1);
+        hipExtLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, e0, e1, 0, a);
+    } else
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, a);
 }
 
 int ctx_gemm_pick_split(int M, int N, int K, int epi)
@@ -699,33 +444,38 @@ int ctx_gemm_pick_split(int M, int N, int K, int epi)
     if (tiles >= 200) return 1;
     if (K < 2048 && tiles > 48) return 1;      // short-K problems: the slab round trip + extra launch costs more than it buys
     int S = 640 / tiles;                       // aim at ~2.5 workgroups per CU
-    int maxS = (K / PK) / 8;                   // keep >= 8 stages per split
+    int maxS = (K / 32) / 8;                   // keep >= 8 stages per split
     if (S > maxS) S = maxS;
     if (S > 32) S = 32;
     return S < 2 ? 1 : S;
 }
 
-// Tile choice: 128x128 when N is a multiple of 128 (no masked columns), else 256x64.
+#include "gemm_tuned.h"
+void ctx_gemm_plan(GemmArgs &a, bool conv)
+{
+    a.tile = -1; a.use8 = -1;
+    static int use_table = -1;
+    if (use_table < 0) { const char *e = getenv("CTX_GEMM_TUNED"); use_table = e ? atoi(e) : 1; }
+    if (use_table) {
+        const int flags = conv ? ((a.stride == 2 ? 1 : 0) | (a.ups ? 2 : 0)) : 0;
+        for (const TunedGemm &t : g_tuned)
+            if (t.conv == (conv ? 1 : 0) && t.M == a.M && t.N == a.N && t.K == a.K && t.flags == flags && t.epi == a.epi) {
+                a.tile = t.tile; a.use8 = t.use8; a.splitk = t.splitk;
+                return;
+            }
+    }
+    a.splitk = ctx_gemm_pick_split(a.M, a.N, a.K, a.epi);
+}
+
+// Tile choice: the largest tile (most flops per staged byte) that still gives the chip >= ~1.5 workgroups per CU once
+// split-K is counted; small problems fall through to tiles with more waves per staged byte.
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
 {
-    if (gemm_impl() == 2 && ctx_gemm8_try(a, conv, s)) {
-        if (a.splitk > 1) {
-            size_t total = (size_t)a.M * (a.N / 4);
-            unsigned nb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-            if (ctx_prof_on()) {
-                hipEvent_t e0, e1;
-                ctx_prof_events(0, &e0, &e1);
-                hipExtLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, e0, e1, 0, a);
-            } else
-                hipLaunchKernelGGL(k_splitk_reduce, dim3(nb), dim3(256), 0, s, a);
-        }
-    } else if (gemm_impl() != 2) {                   // legacy kernels: 4-wave tiles only
-        bool wide = (a.N % 128 == 0) && a.epi == 0;
-        if (conv) { if (wide) launch_gemm<2, 2, true>(a, s); else launch_gemm<4, 1, true>(a, s); }
-        else { if (wide) launch_gemm<2, 2, false>(a, s); else launch_gemm<4, 1, false>(a, s); }
+    const int want8 = g_force_gemm8 >= 0 ? g_force_gemm8 : a.use8;          // -1: gemm8's own heuristic
+    const int want_tile = g_force_tile >= 0 ? g_force_tile : (g_force_gemm8 >= 0 ? -1 : a.tile);
+    if (want_tile < 0 && want8 != 0 && ctx_gemm8_try(a, conv, want8 == 1, s)) {
+        if (a.splitk > 1) launch_reduce(a, s);
     } else {
-        // Tile choice: the largest tile (most flops per LDS-fill byte) that still gives the chip >= ~1.5 workgroups
-        // per CU once split-K is counted; small problems fall through to 128x64 (2 waves) / 64x64 (1 wave) tiles.
         static int big = -1;
         if (big < 0) { const char *e = getenv("CTX_GEMM_BIG"); big = e ? atoi(e) : 1; }
         const int S = a.splitk > 1 && a.part ? a.splitk : 1;
@@ -743,15 +493,23 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
         static int force = -2;
         if (force == -2) { const char *e = getenv("CTX_GEMM_TILE"); force = e ? atoi(e) : -1; }
         if (force >= 0) pick = force;
-#define CTX_LAUNCH(WM_, WN_) do { if (conv) launch_gemm<WM_, WN_, true>(a, s); else launch_gemm<WM_, WN_, false>(a, s); } while (0)
+        if (want_tile >= 0) pick = want_tile;
+        if (a.epi == 1 && (pick == 5 || pick == 6 || pick == 9)) pick = 1;            // GEGLU needs 64-wide wave tiles
+#define CTX_LAUNCH(WM_, WN_, MI_, NI_) do { if (conv) launch_gemm<WM_, WN_, MI_, NI_, true>(a, s); else launch_gemm<WM_, WN_, MI_, NI_, false>(a, s); } while (0)
         switch (pick) {
-        case 0: CTX_LAUNCH(4, 2); break;
-        case 1: CTX_LAUNCH(2, 2); break;
-        case 2: CTX_LAUNCH(4, 1); break;
-        case 3: CTX_LAUNCH(2, 1); break;
-        default: CTX_LAUNCH(1, 1); break;
+        case 0: CTX_LAUNCH(4, 2, 2, 2); break;
+        case 1: CTX_LAUNCH(2, 2, 2, 2); break;
+        case 2: CTX_LAUNCH(4, 1, 2, 2); break;
+        case 3: CTX_LAUNCH(2, 1, 2, 2); break;
+        case 4: CTX_LAUNCH(1, 1, 2, 2); break;
+        case 5: CTX_LAUNCH(2, 2, 1, 1); break;
+        case 6: CTX_LAUNCH(1, 2, 2, 1); break;
+        case 7: CTX_LAUNCH(4, 2, 1, 2); break;
+        case 8: CTX_LAUNCH(2, 2, 1, 2); break;
+        default: CTX_LAUNCH(2, 2, 2, 1); break;
         }
 #undef CTX_LAUNCH
+        if (a.splitk > 1) launch_reduce(a, s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -765,11 +523,12 @@ extern "C" int32_t ctx_gemm_f16(const void *A, const void *Wt, const void *bias,
                                 int32_t N, int32_t K, void *C, ctx_stream_t stream)
 {
     CTX_REQUIRE(A && Wt && C, "gemm: null pointer");
-    CTX_REQUIRE(M > 0 && N > 0 && K > 0 && K % GK == 0 && N % 8 == 0, "gemm: need K%%64==0, N%%8==0 (M=%d N=%d K=%d)", M, N, K);
+    CTX_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0, "gemm: need K%%64==0, N%%8==0 (M=%d N=%d K=%d)", M, N, K);
     CTX_REQUIRE((int64_t)M * K < (1ll << 31) && (int64_t)N * K < (1ll << 31), "gemm: operand too large for 32-bit offsets");
     GemmArgs a = {};
     a.X = (const f16 *)A; a.Wt = (const f16 *)Wt; a.bias = (const f16 *)bias; a.residual = (const f16 *)residual;
     a.out = (f16 *)C; a.M = M; a.N = N; a.K = K; a.ldc = N; a.ldr = N; a.rows_per_batch = 1; a.ldrb = N; a.epi = 0;
+    a.tile = -1; a.use8 = -1;
     return ctx_gemm_dispatch(a, false, (hipStream_t)stream);
 }
 
@@ -778,7 +537,7 @@ extern "C" int32_t ctx_conv3x3_f16(const void *x, const void *w, const void *bia
                                    int32_t stride, int32_t upsample, void *y, ctx_stream_t stream)
 {
     CTX_REQUIRE(x && w && y, "conv3x3: null pointer");
-    CTX_REQUIRE(B > 0 && H > 0 && W > 0 && Cin % GK == 0 && Cout % 8 == 0 && (stride == 1 || stride == 2) &&
+    CTX_REQUIRE(B > 0 && H > 0 && W > 0 && Cin % 64 == 0 && Cout % 8 == 0 && (stride == 1 || stride == 2) &&
                     (upsample == 0 || upsample == 1) && !(upsample && stride == 2),
                 "conv3x3: need Cin%%64==0, Cout%%8==0, stride 1|2 (B=%d H=%d W=%d Cin=%d Cout=%d s=%d up=%d)", B, H, W, Cin, Cout, stride, upsample);
     GemmArgs a = {};
@@ -788,6 +547,7 @@ extern "C" int32_t ctx_conv3x3_f16(const void *x, const void *w, const void *bia
     a.residual = (const f16 *)residual; a.out = (f16 *)y;
     a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Ho * a.Wo; a.ldrb = Cout; a.epi = 0;
     a.H = H; a.W = W; a.Cin = Cin; a.stride = stride; a.ups = upsample;
+    a.tile = -1; a.use8 = -1;
     CTX_REQUIRE((int64_t)B * H * W * Cin < (1ll << 31) && (int64_t)Cout * a.K < (1ll << 31), "conv3x3: tensor too large for 32-bit offsets");
     return ctx_gemm_dispatch(a, true, (hipStream_t)stream);
 }
@@ -858,7 +618,10 @@ extern "C" float ctx_bench_gemm(const void *A, const void *Wt, const void *bias,
     }
     a.epi = epi;
     a.ldc = epi == 1 ? a.N / 2 : a.N; a.ldr = a.N; a.ldrb = a.N;
-    if (splitk < 0) splitk = part ? ctx_gemm_pick_split(a.M, a.N, a.K, epi) : 1;      // what the UNet executor would choose
+    a.tile = -1; a.use8 = -1;
+    if (splitk < 0) {                                       // what the UNet executor would choose
+        if (part) { ctx_gemm_plan(a, conv); splitk = a.splitk; } else splitk = 1;
+    }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < iters + 2; ++i) {

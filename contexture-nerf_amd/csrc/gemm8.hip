@@ -328,11 +328,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
 }
 
 // Launch if the problem suits the 256x256 tile (returns 1), else 0 and the caller falls back to gemm.hip's tiles.
-int ctx_gemm8_try(GemmArgs &a, bool conv, hipStream_t s)
+int ctx_gemm8_try(GemmArgs &a, bool conv, bool force, hipStream_t s)
 {
     // CTX_GEMM8: 0 off, 1 auto (default), 2 force whenever the kernel is applicable (tests); read per call on purpose
     const char *e = getenv("CTX_GEMM8");
-    const int en = e ? atoi(e) : 1;
+    int en = e ? atoi(e) : 1;
+    if (force) en = 2;
     const char *tt = getenv("CTX_GEMM8_MIN_TILES");
     const int min_tiles = tt ? atoi(tt) : 180;
     if (!en) return 0;

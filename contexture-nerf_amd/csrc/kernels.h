@@ -21,15 +21,18 @@ struct GemmArgs {
     float *part;
     int pk;                // K-stage depth chosen by the launcher (32 or 64)
     int krot;              // 1: per-workgroup K rotation (spreads concurrent accesses to shared operand rows)
+    int tile, use8;        // plan: tile id of gemm.hip (-1 = heuristic), 256x256 kernel of gemm8.hip (-1 heuristic / 0 / 1)
     int stage_epi;         // 1: epilogue staged through LDS (whole-line stores / residual reads)
     int mfast;             // 1: consecutive workgroups walk M first (share the weight panel in their XCD's L2)
 };
 
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s);
 // 256x256 8-wave kernel (gemm8.hip): launches and returns 1 when the problem suits it, else 0
-int ctx_gemm8_try(GemmArgs &a, bool conv, hipStream_t s);
-// split-K factor the dispatcher would use for this problem (1 = none); caller provides a.part = S*M*N floats
+int ctx_gemm8_try(GemmArgs &a, bool conv, bool force, hipStream_t s);
+// split-K factor the heuristic would use for this problem (1 = none); caller provides a.part = S*M*N floats
 int ctx_gemm_pick_split(int M, int N, int K, int epi);
+// fills a.splitk / a.tile / a.use8 for a fully described problem: the tuned table (gemm_tuned.h) first, heuristics otherwise
+void ctx_gemm_plan(GemmArgs &a, bool conv);
 int ctx_gemv_f16(const f16 *x, const f16 *w, const f16 *bias, int Bm, int N, int K, int silu_in, int silu_out, f16 *out, hipStream_t s);
 int ctx_concat_f16(const f16 *a, const f16 *b, int64_t M, int Ca, int Cb, f16 *y, hipStream_t s);
 int ctx_transpose_v_f16(const f16 *v, int B, int S, int ld, int heads, int Sp, f16 *vt, hipStream_t s);

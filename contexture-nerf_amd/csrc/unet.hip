@@ -329,7 +329,7 @@ static void op_gemm(ctx_unet *u, const f16 *X, size_t w, size_t bias, bool has_b
     a.M = M; a.N = N; a.K = K; a.ldc = epi == 1 ? N / 2 : N; a.ldr = N; a.rows_per_batch = 1; a.ldrb = N; a.epi = epi;
     note(u, 0, 2.0 * M * N * K);
     size_t mark = u->top;
-    a.splitk = ctx_gemm_pick_split(M, N, K, epi);
+    ctx_gemm_plan(a, false);
     if (a.splitk > 1) a.part = (float *)u->alloc((size_t)a.splitk * M * N * 4);
     RUN(ctx_gemm_dispatch(a, false, u->s));
     u->top = mark;
@@ -345,7 +345,7 @@ static void op_conv(ctx_unet *u, const f16 *x, size_t w, size_t bias, const f16 
     a.H = H; a.W = W; a.Cin = Cin; a.stride = stride; a.ups = ups;
     note(u, 0, 2.0 * a.M * a.N * a.K);
     size_t mark = u->top;
-    a.splitk = ctx_gemm_pick_split(a.M, a.N, a.K, 0);
+    ctx_gemm_plan(a, true);
     if (a.splitk > 1) a.part = (float *)u->alloc((size_t)a.splitk * a.M * a.N * 4);
     RUN(ctx_gemm_dispatch(a, true, u->s));
     u->top = mark;

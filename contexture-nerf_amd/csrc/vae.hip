@@ -210,7 +210,7 @@ static void vgemm(ctx_vae *v, const f16 *X, const f16 *Wt, const f16 *bias, cons
     a.rows_per_batch = 1; a.ldrb = N; a.epi = 0;
     v->flops += 2.0 * M * N * K;
     size_t mark = v->top;
-    a.splitk = ctx_gemm_pick_split(M, N, K, 0);
+    ctx_gemm_plan(a, false);
     if (a.splitk > 1) a.part = (float *)v->alloc((size_t)a.splitk * M * N * 4);
     VRUN(ctx_gemm_dispatch(a, false, v->s));
     v->top = mark;
@@ -224,7 +224,7 @@ static void vconv(ctx_vae *v, const f16 *x, size_t w, size_t bias, const f16 *re
     a.H = H; a.W = W; a.Cin = Cin; a.stride = 1; a.ups = ups;
     v->flops += 2.0 * a.M * a.N * a.K;
     size_t mark = v->top;
-    a.splitk = ctx_gemm_pick_split(a.M, a.N, a.K, 0);
+    ctx_gemm_plan(a, true);
     if (a.splitk > 1) a.part = (float *)v->alloc((size_t)a.splitk * a.M * a.N * 4);
     VRUN(ctx_gemm_dispatch(a, true, v->s));
     v->top = mark;

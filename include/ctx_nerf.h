@@ -228,6 +228,10 @@ float ctx_bench_gemm(const void *A, const void *Wt, const void *bias, const void
                      void *C, int32_t conv_B, int32_t conv_H, int32_t conv_W, int32_t conv_Cin, int32_t conv_flags, int32_t epi,
                      void *part, int32_t splitk, int32_t iters, ctx_stream_t stream);
 
+/* Tuning support (tools/tune_gemm.py): force the tile id of gemm.hip (-1 = planner's choice) and the 256x256 kernel of
+   gemm8.hip (-1 planner, 0 never, 1 whenever applicable) for every following GEMM / conv launch of this process. */
+void ctx_gemm_tune(int32_t tile, int32_t gemm8);
+
 /* Unit-test support: one 32x32 tile through the MFMA fragment maps the kernels assume.
    which 0: f16 32x32x16 (A[32][16], Bt[32][16]); 1: f32 32x32x2 (A[32][2], Bt[32][2]); C[32][32] f32. */
 int32_t ctx_probe_mfma(int32_t which, const void *A, const void *Bt, float *C, ctx_stream_t stream);
