@@ -27,141 +27,6 @@ struct AttnArgs {
     float scale_log2e;
 };
 
-__global__ __launch_bounds__(256) void k_attention(AttnArgs a)
-{
-    __shared__ __attribute__((aligned(16))) f16 Ks[AT_KB * AT_KROW];
-    __shared__ __attribute__((aligned(16))) f16 Vs[64 * AT_VROW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hd = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const int qrow = q0 + r;
-    const bool qok = qrow < a.Sq;
-
-    // Q fragments: B operand, lane (r,h) holds Q[q0+r][16*ks + 8h + j]
-    f16x8 qf[4];
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    {
-        const f16 *qp = a.Q + ((size_t)b * a.Sq + (qok ? qrow : 0)) * a.q_stride + hd * 64 + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = qok ? *(const f16x8 *)(qp + ks * 16) : zero8;
-    }
-    f32x16 o[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) o[d][q] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    const f16 *Kb = a.K + (size_t)b * a.Skv * a.kv_stride + hd * 64;
-    const f16 *Vb = a.Vt + ((size_t)b * a.heads + hd) * 64 * a.Sp;
-    const int ntiles = (a.Skv + AT_KB - 1) / AT_KB;
-    const int srow = tid >> 3, sc = tid & 7;        // staging: 32 rows x 8 chunks per pass
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int k0 = t * AT_KB;
-        __syncthreads();                            // previous tile fully consumed
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int key = srow + 32 * i;
-            f16x8 kv = (k0 + key < a.Skv) ? *(const f16x8 *)(Kb + (size_t)(k0 + key) * a.kv_stride + sc * 8) : zero8;
-            *(f16x8 *)(Ks + key * AT_KROW + sc * 8) = kv;
-            int d = srow + 32 * i;                  // V^T row (feature), 8 keys per chunk; Sp-padded, zero filled
-            f16x8 vv = *(const f16x8 *)(Vb + (size_t)d * a.Sp + k0 + sc * 8);
-            f16x4 lo = {vv[0], vv[1], vv[2], vv[3]}, hi = {vv[4], vv[5], vv[6], vv[7]};
-            *(f16x4 *)(Vs + d * AT_VROW + sc * 8) = lo;
-            *(f16x4 *)(Vs + d * AT_VROW + sc * 8 + 4) = hi;
-        }
-        __syncthreads();
-
-        // ---- S^T = K . Q^T : two 32-key blocks -------------------------------------------------
-        f32x16 s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s[kb][q] = 0.f;
-            const f16 *kp = Ks + (kb * 32 + r) * AT_KROW + 8 * h;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                f16x8 kf = *(const f16x8 *)(kp + ks * 16);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
-            }
-        }
-        // ---- online softmax over this lane's query column ------------------------------------------
-        // raw scores stay unscaled; p = exp2(s*c - m) is one FMA + one v_exp_f32 per element (c = scale*log2 e)
-        const float c = a.scale_log2e;
-        if (k0 + AT_KB > a.Skv) {                    // only the last tile can hold padded keys
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    int key = k0 + kb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                    if (key >= a.Skv) s[kb][q] = -INFINITY;
-                }
-        }
-        float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-        for (int q = 1; q < 16; ++q) mx = fmaxf(mx, fmaxf(s[0][q], s[1][q]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
-        float m_new = fmaxf(m_run, mx);
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][q], c, -m_new));
-                s[kb][q] = p;
-                psum += p;
-            }
-        psum += __shfl_xor(psum, 32, 64);
-        if (__any(m_new != m_run)) {                 // wave-uniform: rescale only when some row's max moved
-            float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) o[d][q] *= alpha;
-        }
-        l_run += psum;
-        m_run = m_new;
-
-        // ---- O^T += V^T . P^T --------------------------------------------------------------------------
-        // P^T as B operand of k-step st (16 keys) of block kb: elements j = registers 8*st + j, whose key is
-        // 16*st + 8*(j>>2) + 4h + (j&3); the V^T (A operand) element j must be that same key.
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                f16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (f16)s[kb][8 * st + j];
-#pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    const f16 *vp = Vs + (d * 32 + r) * AT_VROW + kb * 32 + 16 * st + 4 * h;
-                    f16x4 v0 = *(const f16x4 *)(vp);
-                    f16x4 v1 = *(const f16x4 *)(vp + 8);
-                    f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[d], 0, 0, 0);
-                }
-            }
-    }
-
-    // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane = query, registers walk d ------------------------------
-    if (qok) {
-        float inv = 1.0f / l_run;
-        f16 *op = a.O + ((size_t)b * a.Sq + qrow) * a.o_stride + hd * 64;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f16x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (f16)(o[d][4 * g + j] * inv);
-                *(f16x4 *)(op + d * 32 + 8 * g + 4 * h) = v;
-            }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // LDS-DMA variant (default): K and V^T tiles arrive by global_load_lds into a ring of AT_NS stages (1 KiB pieces of
 // 8 rows x 128 B, chunk swizzle c ^ ((row>>1)&7) on the source address and on the fragment reads), prefetch distance
@@ -172,9 +37,13 @@ typedef __attribute__((address_space(3))) void *alptr_t;
 
 
 // One 64-key tile of the online-softmax recurrence for this wave's 32 queries (MASK only for the last, ragged tile).
+// V^T arrives with the keys of every 16-group stored as [0-3, 8-11, 4-7, 12-15] (ctx_transpose_v_f16), so the 8 keys a
+// lane half needs for one PV k-step are one 16-byte chunk (the same conflict-free read as the K fragments).  The row sums
+// l = sum_k p ride on the matrix pipe: one extra MFMA per k-step with an all-ones A operand accumulates, in every row
+// of `ls`, the sum of exactly the fp16-rounded P the PV product uses; the VALU is this kernel's critical resource.
 template <bool MASK>
 __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 *__restrict__ Vs, int k0, int Skv, int r, int h,
-                                          int swz, float c, const f16x8 (&qf)[4], f32x16 (&o)[2], float &m_run, float &l_run)
+                                          int swz, float c, const f16x8 (&qf)[4], f32x16 (&o)[2], f32x16 &ls, float &m_run)
 {
     f32x16 s[2];
 #pragma unroll
@@ -202,26 +71,22 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
     for (int q = 1; q < 16; ++q) mx = fmaxf(mx, fmaxf(s[0][q], s[1][q]));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
     float m_new = fmaxf(m_run, mx);
-    float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][q], c, -m_new));
-            s[kb][q] = p;
-            psum += p;
-        }
-    psum += __shfl_xor(psum, 32, 64);
-    if (__any(m_new != m_run)) {                     // wave-uniform: rescale only when some row's max moved
-        float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
+        for (int q = 0; q < 16; ++q) s[kb][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][q], c, -m_new));
+    // rescale: branch-free on purpose (a conditional update makes hipcc copy all 48 accumulator registers on the
+    // fall-through path of every tile, which costs more than the 33 multiplies)
+    {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 1.0 when the max did not move; 0 on the first tile
+        ls[0] *= alpha;                              // every row of ls holds the same sums; row 0 is the one read
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int q = 0; q < 16; ++q) o[d][q] *= alpha;
     }
-    l_run += psum;
     m_run = m_new;
+    const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -229,15 +94,13 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
             f16x8 pf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = (f16)s[kb][8 * st + j];
+            const int ch = ((4 * kb + 2 * st + h) ^ swz) * 8;
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
-                const f16 *vr = Vs + (d * 32 + r) * 64 + 4 * h;
-                const int c0 = kb * 4 + 2 * st;
-                f16x4 v0 = *(const f16x4 *)(vr + ((c0 ^ swz) * 8));
-                f16x4 v1 = *(const f16x4 *)(vr + (((c0 + 1) ^ swz) * 8));
-                f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                f16x8 vf = *(const f16x8 *)(Vs + (d * 32 + r) * 64 + ch);
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[d], 0, 0, 0);
             }
+            ls = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, ls, 0, 0, 0);
         }
 }
 
@@ -265,7 +128,10 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int q = 0; q < 16; ++q) o[d][q] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 ls;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ls[q] = 0.f;
+    float m_run = -INFINITY;
 
     const int ntiles = (a.Skv + AT_KB - 1) / AT_KB;
     // issue-side state: this wave moves pieces {wave, wave+4} of the K tile and of the V^T tile
@@ -304,25 +170,29 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
 
     const int swz = (r >> 1) & 7;
     const float c = a.scale_log2e;
-    for (int t0 = 0; t0 < ntiles; t0 += AT_NS) {
-#pragma unroll
-        for (int u = 0; u < AT_NS; ++u) {
-            const int t = t0 + u;
-            if (t < ntiles) {
-                int newer = issued - 1 - t;
-                if (AT_NS >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-                else if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (issued < ntiles) issue((u + AT_NS - 1) % AT_NS);
-                const f16 *Ks = ring + u * (2 * 64 * 64);
-                if (t * AT_KB + AT_KB > a.Skv) attn_tile<true>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, c, qf, o, m_run, l_run);
-                else attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, c, qf, o, m_run, l_run);
-            }
-        }
+    // one copy of the tile body in the loop (runtime ring slot): full tiles first, the ragged tile peeled off the end, so
+    // the accumulators keep one fixed register block (unrolled / two-variant bodies made hipcc shuffle all 48 of them)
+    const int nfull = a.Skv / AT_KB;
+    int slot = 0;
+    for (int t = 0; t < nfull; ++t) {
+        const int newer = issued - 1 - t;
+        if (AT_NS >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+        else if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (issued < ntiles) issue(slot == 0 ? AT_NS - 1 : slot - 1);          // the slot tile t-1 used
+        const f16 *Ks = ring + slot * (2 * 64 * 64);
+        attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, c, qf, o, ls, m_run);
+        slot = slot + 1 == AT_NS ? 0 : slot + 1;
+    }
+    if (nfull < ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const f16 *Ks = ring + slot * (2 * 64 * 64);
+        attn_tile<true>(Ks, Ks + 64 * 64, nfull * AT_KB, a.Skv, r, h, swz, c, qf, o, ls, m_run);
     }
     if (qok) {
-        float inv = 1.0f / l_run;
+        float inv = 1.0f / ls[0];
         f16 *op = a.O + ((size_t)b * a.Sq + qrow) * a.o_stride + hd * 64;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -343,11 +213,9 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq,
     a.Q = Q; a.K = K; a.Vt = Vt; a.O = O; a.Sq = Sq; a.Skv = Skv; a.Sp = Sp; a.heads = heads;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
-    static int impl = -1;
-    if (impl < 0) { const char *e = getenv("CTX_ATTN_IMPL"); impl = e ? atoi(e) : 1; }
     static int ns = -1;
     if (ns < 0) { const char *e = getenv("CTX_ATTN_NS"); ns = e ? atoi(e) : 3; }
-    auto kern = impl == 1 ? (ns == 2 ? k_attention_dma<2> : (ns == 4 ? k_attention_dma<4> : k_attention_dma<3>)) : k_attention;
+    auto kern = ns == 2 ? k_attention_dma<2> : (ns == 4 ? k_attention_dma<4> : k_attention_dma<3>);
     if (ctx_prof_on()) {
         hipEvent_t e0, e1;
         ctx_prof_events(1, &e0, &e1);
@@ -378,7 +246,7 @@ extern "C" int32_t ctx_attention_f16(const void *Q, const void *K, const void *V
                 "attention: bad strides/sizes (head_dim is fixed at 64)");
     int Sp = cdiv(Skv, AT_KB) * AT_KB;
     hipStream_t s = (hipStream_t)stream;
-    ctx_transpose_v_f16((const f16 *)V, B, Skv, kv_stride, heads, Sp, (f16 *)vt_ws, s);
+    ctx_transpose_v_f16((const f16 *)V, B, Skv, kv_stride, heads, Sp, 1, (f16 *)vt_ws, s);
     return ctx_attention_core((const f16 *)Q, (const f16 *)K, (const f16 *)vt_ws, B, Sq, Skv, Sp, heads, q_stride, kv_stride,
                               scale, (f16 *)O, o_stride, s);
 }

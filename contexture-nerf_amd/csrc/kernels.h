@@ -35,7 +35,7 @@ int ctx_gemm_pick_split(int M, int N, int K, int epi);
 void ctx_gemm_plan(GemmArgs &a, bool conv);
 int ctx_gemv_f16(const f16 *x, const f16 *w, const f16 *bias, int Bm, int N, int K, int silu_in, int silu_out, f16 *out, hipStream_t s);
 int ctx_concat_f16(const f16 *a, const f16 *b, int64_t M, int Ca, int Cb, f16 *y, hipStream_t s);
-int ctx_transpose_v_f16(const f16 *v, int B, int S, int ld, int heads, int Sp, f16 *vt, hipStream_t s);
+int ctx_transpose_v_f16(const f16 *v, int B, int S, int ld, int heads, int Sp, int perm, f16 *vt, hipStream_t s);
 int ctx_f32_to_f16(const float *x, int64_t n, f16 *y, hipStream_t s);
 int ctx_time_embed_f16(const float *t, int B, int dim, f16 *out, hipStream_t s);
 int ctx_conv_in_f16(const float *x, const f16 *w, const f16 *bias, int B, int Cin, int H, int W, int Cout, f16 *y, hipStream_t s);

@@ -349,8 +349,10 @@ int ctx_concat_f16(const f16 *a, const f16 *b, int64_t M, int Ca, int Cb, f16 *y
     return CTX_OK;
 }
 
-// V [B, S, ld] (head slice at column h*64) -> Vt [B, heads, 64, Sp] (keys contiguous, zero padded to Sp).
-__global__ __launch_bounds__(256) void k_transpose_v(const f16 *__restrict__ v, int S, int ld, int heads, int Sp,
+// V [B, S, ld] (head slice at column h*64) -> Vt [B, heads, 64, Sp] (keys contiguous, zero padded to Sp).  Inside every
+// group of 16 keys the order is [0-3, 8-11, 4-7, 12-15] when perm != 0 (attention's layout; perm = 0 is a plain transpose): the 8 keys one lane half feeds to a PV MFMA k-step (the P
+// fragment is a 32x32 accumulator: keys 8(j>>2) + 4h + (j&3)) are then one 16-byte chunk (attention.hip: attn_tile).
+__global__ __launch_bounds__(256) void k_transpose_v(const f16 *__restrict__ v, int S, int ld, int heads, int Sp, int perm,
                                                      f16 *__restrict__ vt)
 {
     __shared__ f16 tile[64][66];
@@ -368,14 +370,14 @@ __global__ __launch_bounds__(256) void k_transpose_v(const f16 *__restrict__ v, 
         int d = (threadIdx.x >> 3) + 32 * i, c = threadIdx.x & 7;
         f16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = tile[c * 8 + j][d];
+        for (int j = 0; j < 8; ++j) o[j] = perm ? tile[16 * (c >> 1) + 8 * (j >> 2) + 4 * (c & 1) + (j & 3)][d] : tile[c * 8 + j][d];
         if (s0 + c * 8 < Sp) *(f16x8 *)(vt + (((size_t)b * heads + hd) * 64 + d) * Sp + s0 + c * 8) = o;
     }
 }
 
-int ctx_transpose_v_f16(const f16 *v, int B, int S, int ld, int heads, int Sp, f16 *vt, hipStream_t s)
+int ctx_transpose_v_f16(const f16 *v, int B, int S, int ld, int heads, int Sp, int perm, f16 *vt, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_transpose_v, dim3(cdiv(Sp, 64), heads, B), dim3(256), 0, s, v, S, ld, heads, Sp, vt);
+    hipLaunchKernelGGL(k_transpose_v, dim3(cdiv(Sp, 64), heads, B), dim3(256), 0, s, v, S, ld, heads, Sp, perm, vt);
     return CTX_OK;
 }
 

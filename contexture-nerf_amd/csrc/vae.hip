@@ -285,7 +285,7 @@ static int vae_run(ctx_vae *v, const float *z, int B, int H, int W, float *img)
                 (void)hipMemcpy2DAsync(qb, (size_t)top * 2, base, (size_t)3 * top * 2, (size_t)top * 2, S, hipMemcpyDeviceToDevice, v->s);
                 (void)hipMemcpy2DAsync(kb, (size_t)top * 2, base + top, (size_t)3 * top * 2, (size_t)top * 2, S, hipMemcpyDeviceToDevice, v->s);
             }
-            VRUN(ctx_transpose_v_f16(base + 2 * top, 1, S, 3 * top, top / 64, S, vt, v->s));
+            VRUN(ctx_transpose_v_f16(base + 2 * top, 1, S, 3 * top, top / 64, S, 0, vt, v->s));
             vgemm(v, qb, kb, nullptr, nullptr, S, S, top, sc);
             if (!v->dry) hipLaunchKernelGGL(k_softmax_rows, dim3(S), dim3(256), 0, v->s, sc, S, 1.4426950408889634f / sqrtf((float)top), pr);
             vgemm(v, pr, vt, nullptr, nullptr, S, top, S, att ? att + (size_t)b * S * top : nullptr);
