@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a)
 // tile ids (CTX_GEMM_TILE / ctx_gemm_tune): WM x WN waves of MI x NI 32x32 blocks
 //   0: 256x128 8w   1: 128x128 4w   2: 256x64 4w   3: 128x64 2w   4: 64x64 1w
 //   5: 64x64 4w (32x32 per wave)   6: 64x64 2w (64x32)   7: 128x128 8w (32x64)   8: 64x128 4w (32x64)   9: 128x64 4w (64x32)
+//   10-14: 64-deep K stages, ring of 3: 256x128 16w (32x64) | 256x128 16w (64x32) | 256x128 8w | 128x128 16w (32x32) | 128x128 8w
 static int g_force_tile = -1, g_force_gemm8 = -1;
 extern "C" void ctx_gemm_tune(int32_t tile, int32_t gemm8)
 {
@@ -388,7 +389,7 @@ extern "C" void ctx_gemm_tune(int32_t tile, int32_t gemm8)
     g_force_gemm8 = gemm8;          // -1: heuristic, 0: never, 1: always when applicable
 }
 
-template <int WM, int WN, int MI, int NI, bool CONV>
+template <int WM, int WN, int MI, int NI, bool CONV, int NS = 4, int PKT = 32>
 static void launch_gemm(GemmArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
@@ -403,12 +404,12 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
     static int stg = -1;
     if (stg < 0) { const char *e = getenv("CTX_GEMM_STAGE_EPI"); stg = e ? atoi(e) : 1; }
     a.stage_epi = stg && (a.ldc % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0);
-    a.pk = 32; a.krot = 0;
+    a.pk = PKT; a.krot = 0;
     constexpr int NT = 64 * WM * WN;
-    constexpr size_t ring = (size_t)4 * (BM + BN) * 32 * sizeof(f16);
+    constexpr size_t ring = (size_t)NS * (BM + BN) * PKT * sizeof(f16);
     constexpr size_t patch = (size_t)WM * WN * 32 * (32 * NI + 4) * sizeof(float);
     constexpr size_t lds = ring > patch ? ring : patch;
-    auto kern = k_gemm_pipe<WM, WN, MI, NI, CONV, 4, 32>;
+    auto kern = k_gemm_pipe<WM, WN, MI, NI, CONV, NS, PKT>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -494,7 +495,8 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
         if (force == -2) { const char *e = getenv("CTX_GEMM_TILE"); force = e ? atoi(e) : -1; }
         if (force >= 0) pick = force;
         if (want_tile >= 0) pick = want_tile;
-        if (a.epi == 1 && (pick == 5 || pick == 6 || pick == 9)) pick = 1;            // GEGLU needs 64-wide wave tiles
+        if (a.epi == 1 && (pick == 5 || pick == 6 || pick == 9 || pick == 11 || pick == 13)) pick = 1;   // GEGLU needs 64-wide wave tiles
+        if (pick >= 10 && (a.K % 64 != 0 || (conv && a.Cin % 64 != 0))) pick = 1;   // 64-deep stages
 #define CTX_LAUNCH(WM_, WN_, MI_, NI_) do { if (conv) launch_gemm<WM_, WN_, MI_, NI_, true>(a, s); else launch_gemm<WM_, WN_, MI_, NI_, false>(a, s); } while (0)
         switch (pick) {
         case 0: CTX_LAUNCH(4, 2, 2, 2); break;
@@ -506,7 +508,14 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
         case 6: CTX_LAUNCH(1, 2, 2, 1); break;
         case 7: CTX_LAUNCH(4, 2, 1, 2); break;
         case 8: CTX_LAUNCH(2, 2, 1, 2); break;
-        default: CTX_LAUNCH(2, 2, 2, 1); break;
+        case 9: CTX_LAUNCH(2, 2, 2, 1); break;
+#define CTX_LAUNCH64(WM_, WN_, MI_, NI_) do { if (conv) launch_gemm<WM_, WN_, MI_, NI_, true, 3, 64>(a, s); else launch_gemm<WM_, WN_, MI_, NI_, false, 3, 64>(a, s); } while (0)
+        case 10: CTX_LAUNCH64(8, 2, 1, 2); break;     // 256x128, 16 waves (32x64), 64-deep stages
+        case 11: CTX_LAUNCH64(4, 4, 2, 1); break;     // 256x128, 16 waves (64x32)
+        case 12: CTX_LAUNCH64(4, 2, 2, 2); break;     // 256x128, 8 waves
+        case 13: CTX_LAUNCH64(4, 4, 1, 1); break;     // 128x128, 16 waves (32x32)
+        default: CTX_LAUNCH64(4, 2, 1, 2); break;     // 14: 128x128, 8 waves (32x64)
+#undef CTX_LAUNCH64
         }
 #undef CTX_LAUNCH
         if (a.splitk > 1) launch_reduce(a, s);
