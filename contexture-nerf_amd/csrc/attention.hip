@@ -75,15 +75,17 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) s[kb][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][q], c, -m_new));
-    // rescale: branch-free on purpose (a conditional update makes hipcc copy all 48 accumulator registers on the
-    // fall-through path of every tile, which costs more than the 33 multiplies)
-    {
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 1.0 when the max did not move; 0 on the first tile
-        ls[0] *= alpha;                              // every row of ls holds the same sums; row 0 is the one read
+    // rescale only when some row's max moved (wave-uniform branch).  The multiplies are inline asm with tied operands:
+    // written as C++ the compiler multiplies out of place and then copies all 48 accumulator registers on the
+    // fall-through path of every tile, which costs more than multiplying unconditionally.
+    if (__any(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 on the first tile (m_run = -inf)
+        // s_nop: alpha comes straight from v_exp_f32 (transcendental -> VALU use needs a wait state hipcc cannot see into)
+        asm volatile("s_nop 1\n\tv_mul_f32 %0, %0, %1" : "+v"(ls[0]) : "v"(alpha));
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) o[d][q] *= alpha;
+            for (int q = 0; q < 16; ++q) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[d][q]) : "v"(alpha));
     }
     m_run = m_new;
     const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
@@ -216,6 +218,17 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq,
     static int ns = -1;
     if (ns < 0) { const char *e = getenv("CTX_ATTN_NS"); ns = e ? atoi(e) : 3; }
     auto kern = ns == 2 ? k_attention_dma<2> : (ns == 4 ? k_attention_dma<4> : k_attention_dma<3>);
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char *e = getenv("CTX_ATTN_DEBUG"); dbg = e ? atoi(e) : 0;
+        if (dbg) {
+            int nb = 0;
+            hipFuncAttributes fa;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, 0);
+            (void)hipFuncGetAttributes(&fa, (const void *)kern);
+            fprintf(stderr, "[ctx] attention: %d blocks/CU by the occupancy API, %d VGPRs, %zu B static LDS\n", nb, fa.numRegs, fa.sharedSizeBytes);
+        }
+    }
     if (ctx_prof_on()) {
         hipEvent_t e0, e1;
         ctx_prof_events(1, &e0, &e1);

@@ -6,7 +6,10 @@ import torch
 from contexture_nerf_amd import _lib as L
 lib = L.load(); dev = torch.device('cuda:0')
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-for (B, S, Skv, heads) in [(2, 9216, 9216, 5), (2, 2304, 2304, 10), (2, 576, 576, 20), (2, 9216, 77, 5)]:
+shapes = [(2, 9216, 9216, 5), (2, 2304, 2304, 10), (2, 576, 576, 20), (2, 9216, 77, 5)]
+if len(sys.argv) > 2:
+    shapes = [shapes[int(i)] for i in sys.argv[2].split(',')]
+for (B, S, Skv, heads) in shapes:
     C = heads * 64
     g = torch.Generator(device=dev).manual_seed(0)
     qkv = torch.randn(B, S, 3 * C, generator=g, device=dev).half()
