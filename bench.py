@@ -37,6 +37,7 @@ def parse():
     p.add_argument("--guidance", type=float, default=10.0)
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-latent", type=int, default=0, help="latent side of the CPU sample (0 = auto)")
+    p.add_argument("--vae", type=int, default=1, help="also time the once-per-view VAE decode (outside the step loop)")
     return p.parse_args()
 
 
@@ -155,16 +156,18 @@ def main():
 
     # once-per-view tail of img2img_step: VAE decode of the denoised latents (stable_diffusion_depth.py:567), timed outside
     # the step loop
-    from contexture_nerf_amd.vae import AutoencoderKL
-    vae = AutoencoderKL(device=dev, seed=0)
-    zlat = state["lat"] / 0.18215
-    vae.decode(zlat); torch.cuda.synchronize()
-    tv = time.perf_counter()
-    img = vae.decode(zlat).sample
-    torch.cuda.synchronize()
-    vae_ms = (time.perf_counter() - tv) * 1e3
-    assert torch.isfinite(img).all()
-    vae_tflop = vae.flops() / 1e12
+    vae_ms, vae_tflop = None, None
+    if a.vae:
+        from contexture_nerf_amd.vae import AutoencoderKL
+        vae = AutoencoderKL(device=dev, seed=0)
+        zlat = state["lat"] / 0.18215
+        vae.decode(zlat); torch.cuda.synchronize()
+        tv = time.perf_counter()
+        img = vae.decode(zlat).sample
+        torch.cuda.synchronize()
+        vae_ms = (time.perf_counter() - tv) * 1e3
+        assert torch.isfinite(img).all()
+        vae_tflop = vae.flops() / 1e12
 
     # multi-GPU exchange step of the path (once per mesh, not per denoise step): atlas all-reduce, timed separately
     atlas_ms = None
@@ -175,6 +178,17 @@ def main():
         dist.all_reduce(atlas); torch.cuda.synchronize()
         atlas_ms = (time.perf_counter() - t1) * 1e3
 
+    # HBM-side bytes per launch of the dominant kernel family: PMC counters cannot be collected from inside this process,
+    # so the figure is the committed result of tools/pmc_traffic.sh (same command line, same workload) when present
+    traffic, traffic_src = None, None
+    tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            traffic = round(tj["families"]["gemm_conv"]["bytes_per_launch"])
+            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per GEMM/conv launch)"
+        except Exception:
+            traffic = None
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         out = {
@@ -188,14 +202,15 @@ def main():
                        "latent": S, "cfg_batch": 2, "ctx_len": 77, "views_per_rank": 1, "parallelism": f"view-shard x{world}"},
             "tflops_per_step": round(total_fl / 1e12, 4),
             "step_tflops_per_s": round(total_fl / 1e12 / (elapsed / a.steps), 2),
-            "vae_decode_ms": round(vae_ms, 3), "vae_decode_tflop": round(vae_tflop, 3),
-            "sec_per_view": round((51 * ms_per_step + vae_ms) / 1e3, 3),
-            "sec_per_mesh_6_views_est": round(-(-6 // world) * (51 * ms_per_step + vae_ms) / 1e3, 3),
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_f16 (GEMM + implicit-GEMM conv3x3, v_mfma_f32_32x32x16_f16)",
+            "vae_decode_ms": round(vae_ms, 3) if vae_ms is not None else None,
+            "vae_decode_tflop": round(vae_tflop, 3) if vae_tflop is not None else None,
+            "sec_per_view": round((51 * ms_per_step + (vae_ms or 0.0)) / 1e3, 3),
+            "sec_per_mesh_6_views_est": round(-(-6 // world) * (51 * ms_per_step + (vae_ms or 0.0)) / 1e3, 3),
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_pipe<...> + k_gemm8 (+ k_splitk_reduce): fp16 MFMA GEMM / implicit-GEMM conv3x3 of the UNet",
                          "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
-                         "traffic": None, "launches_per_step": gemm_n, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_n, 1), 2),
+                         "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": gemm_n, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_n, 1), 2),
                          "flops_per_launch_avg": round(gemm_fl / max(gemm_n, 1) / 1e9, 3), "kernel_ms_per_step": round(gemm_ms, 3)},
-            "attention": {"kernel": "k_attention", "achieved": round(fl["attention"][1] / (att_ms * 1e-3) / 1e12, 2) if att_ms > 0 else 0.0,
+            "attention": {"kernel": "k_attention_dma", "achieved": round(fl["attention"][1] / (att_ms * 1e-3) / 1e12, 2) if att_ms > 0 else 0.0,
                           "unit": "TFLOP/s", "launches_per_step": att_n, "kernel_ms_per_step": round(att_ms, 3)},
         }
         if atlas_ms is not None:

@@ -177,6 +177,67 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
     }
 }
 
+// Small-tensor GroupNorm in ONE kernel: when a group's channels are whole 16-byte chunks (C/G % 8 == 0) and one
+// (batch, group) slab fits a workgroup's registers (<= GN_FT x GN_FU chunks), a workgroup loads its slab once, reduces
+// it (fixed order: lane partials -> DPP wave sums -> 8 wave partials), and writes the normalised slab from registers.
+// At the UNet's two deepest levels this replaces two latency-bound launches and one re-read of the tensor.
+#define GN_FT 512
+#define GN_FU 12
+__global__ __launch_bounds__(GN_FT) void k_gn_fused(const f16 *__restrict__ x, const f16 *__restrict__ gamma,
+                                                    const f16 *__restrict__ beta, int HW, int C, int G, float eps, int silu,
+                                                    f16 *__restrict__ y)
+{
+    __shared__ float s_red[2][GN_FT / 64];
+    __shared__ float s_gb[2][GN_MAX_C / 16];          // this group's gamma, beta (cg <= 256 channels)
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cg = C / G, cpg = cg / 8;                // chunks per pixel in this group
+    const int total = HW * cpg;
+    const f16 *xb = x + (size_t)b * HW * C + g * cg;
+    f16 *yb = y + (size_t)b * HW * C + g * cg;
+    for (int c = threadIdx.x; c < cg; c += GN_FT) { s_gb[0][c] = (float)gamma[g * cg + c]; s_gb[1][c] = (float)beta[g * cg + c]; }
+    f16x8 v[GN_FU];
+    int off[GN_FU];
+#pragma unroll
+    for (int u = 0; u < GN_FU; ++u) {
+        const int i = min((int)threadIdx.x + GN_FT * u, total - 1);
+        const int p = i / cpg, c = i - p * cpg;
+        off[u] = p * C + c * 8;
+        v[u] = *(const f16x8 *)(xb + off[u]);          // unconditional (clamped), all in flight
+    }
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int u = 0; u < GN_FU; ++u)
+        if ((int)threadIdx.x + GN_FT * u < total) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float f = (float)v[u][j]; s += f; q += f * f; }
+        }
+    s = wave_sum_dpp(s); q = wave_sum_dpp(q);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[0][wave] = s; s_red[1][wave] = q; }
+    __syncthreads();
+    float ss = 0.f, qq = 0.f;
+#pragma unroll
+    for (int w = 0; w < GN_FT / 64; ++w) { ss += s_red[0][w]; qq += s_red[1][w]; }
+    const float n = (float)HW * (float)cg;
+    const float mean = ss / n;
+    const float rstd = rsqrtf(fmaxf(qq / n - mean * mean, 0.f) + eps);
+#pragma unroll
+    for (int u = 0; u < GN_FU; ++u) {
+        const int i = (int)threadIdx.x + GN_FT * u;
+        if (i < total) {
+            const int c0 = (i % cpg) * 8;
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = ((float)v[u][j] - mean) * rstd * s_gb[0][c0 + j] + s_gb[1][c0 + j];
+                if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+                o[j] = (f16)t;
+            }
+            *(f16x8 *)(yb + off[u]) = o;
+        }
+    }
+}
+
 extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups)
 {
     return ((int64_t)B * GN_MAX_SPLITS * groups * 2 + (int64_t)B * 2 * GN_MAX_C) * 4;
@@ -190,6 +251,17 @@ extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const voi
                     256 % groups == 0 && (256 / groups & (256 / groups - 1)) == 0,
                 "groupnorm: unsupported B=%d HW=%d C=%d groups=%d", B, HW, C, groups);
     hipStream_t s = (hipStream_t)stream;
+    {
+        static int fuse = -1;
+        if (fuse < 0) { const char *e = getenv("CTX_GN_FUSED"); fuse = e ? atoi(e) : 1; }
+        const int cg = C / groups;
+        if (fuse && cg % 8 == 0 && cg <= GN_MAX_C / 16 && (int64_t)HW * (cg / 8) <= GN_FT * GN_FU) {
+            hipLaunchKernelGGL(k_gn_fused, dim3(groups, B), dim3(GN_FT), 0, s, (const f16 *)x, (const f16 *)gamma, (const f16 *)beta, HW, C,
+                               groups, eps, silu, (f16 *)y);
+            CTX_CHECK_LAUNCH("groupnorm");
+            return CTX_OK;
+        }
+    }
     int c8n = C / 8;
     int PL = 1024 / c8n;                                      // pixel lanes: ~1000 threads per block
     if (PL < 1) PL = 1;

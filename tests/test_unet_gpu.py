@@ -139,7 +139,8 @@ def test_gemm_geglu_and_splitk(dev, M, C4, K, splitk, forced):
 
 
 @pytest.mark.parametrize("B,HW,Cc,G,silu", [(2, 256, 64, 32, 1), (2, 1024, 320, 32, 1), (1, 144, 1280, 32, 0),
-                                            (2, 400, 2560, 32, 1), (2, 576, 1920, 32, 1), (2, 100, 960, 32, 0)])
+                                            (2, 400, 2560, 32, 1), (2, 576, 1920, 32, 1), (2, 100, 960, 32, 0),
+                                            (2, 576, 1280, 32, 1), (2, 1229, 1280, 32, 0)])
 def test_groupnorm(dev, B, HW, Cc, G, silu):
     L, lib = _lib()
     g = torch.Generator().manual_seed(Cc)
