@@ -1,0 +1,19 @@
+#!/bin/bash
+# Regenerates everything under profiles/ on a GPU box (run through gpurun; outputs land in gpurun_out/prof_refresh/ and are
+# copied into profiles/ afterwards by the caller).  Usage: tools/refresh_profiles.sh
+set -x
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_refresh
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+bash tools/pmc_traffic.sh prof_refresh/traffic > /dev/null 2>&1
+cp gpurun_out/prof_refresh/traffic.json profiles/r01_pmc_traffic.json      # so that the default bench line below can quote it
+timeout -k 10 300 python3 bench.py > $OUT/bench_default.log 2>&1
+tail -1 $OUT/bench_default.log > $OUT/r01_bench_default.json
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/unet -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --vae 0 > $OUT/unet.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/geom -- python3 $GRAFT_REPO_ROOT/tools/bench_geometry.py > $OUT/geom.log 2>&1
+cd $GRAFT_REPO_ROOT
+python3 tools/prof_summary.py $OUT/unet 8 70 > $OUT/r01_bench_by_kernel_and_grid.txt 2>&1
+timeout -k 10 200 python3 tools/bench_geometry.py --cpu 1 > $OUT/r01_geometry_bench.jsonl 2>&1
+timeout -k 10 120 python3 tools/bench_gemm.py 3 all > $OUT/r01_gemm_layers.txt 2>&1
+ls $OUT
