@@ -138,6 +138,66 @@ def test_gemm_geglu_and_splitk(dev, M, C4, K, splitk, forced):
             os.environ["CTX_GEMM8"] = old
 
 
+def _tuned_entries():
+    import os, re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "contexture-nerf_amd", "csrc", "gemm_tuned.h")
+    out = []
+    for line in open(path):
+        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (-?\d+), (-?\d+), (\d+)\}", line)
+        if m:
+            out.append(tuple(int(x) for x in m.groups()))
+    return out
+
+
+def test_tuned_plans_against_torch(dev):
+    """Every plan of the tuned table (tile form, 256x256 kernel, split-K) at its exact full-size shape against an fp32 torch
+    reference computed on the same GPU from the same fp16-rounded operands (bias + residual epilogue, GEGLU where planned)."""
+    L, lib = _lib()
+    entries = _tuned_entries()
+    assert len(entries) > 50
+    g = torch.Generator(device=dev).manual_seed(11)
+    part = torch.empty(384 << 20, dtype=torch.uint8, device=dev)
+    checked = 0
+    for conv, M, N, K, flags, epi, tile, use8, S in entries:
+        if conv:
+            Cin = K // 9
+            st, up = (2 if flags & 1 else 1), (1 if flags & 2 else 0)
+            # recover the input grid: M = 2 * Ho * Wo, square; Ho = (H << up - 1) // st + 1
+            Ho = int(round((M // 2) ** 0.5)); assert 2 * Ho * Ho == M
+            H = Ho // 2 if up else (Ho * 2 if st == 2 else Ho)
+            x = torch.randn(2, H, H, Cin, generator=g, device=dev).half()
+            cb = (2, H, H, Cin, flags)
+        else:
+            x = torch.randn(M, K, generator=g, device=dev).half()
+            cb = (0, 0, 0, 0, 0)
+        w = (torch.randn(N, K, generator=g, device=dev) / K ** 0.5).half()
+        No = N // 2 if epi else N
+        y = torch.zeros(M, No, dtype=torch.float16, device=dev)
+        res = torch.randn(M, No, generator=g, device=dev).half() if not epi else None
+        bias = torch.randn(N, generator=g, device=dev).half()
+        ms = lib.ctx_bench_gemm(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(res), M, N, K, L.ptr(y), *cb, epi, L.ptr(part), -1, 1, L.stream())
+        assert ms > 0, lib.ctx_last_error()
+        if conv:
+            xin = x.float().permute(0, 3, 1, 2)
+            if up:
+                xin = F.interpolate(xin, scale_factor=2.0, mode='nearest')
+            wt = w.float().view(N, 3, 3, Cin).permute(0, 3, 1, 2)
+            want = F.conv2d(xin, wt, bias.float(), stride=st, padding=1).permute(0, 2, 3, 1).reshape(M, N) + res.float()
+        elif epi:
+            full = x.float() @ w.float().T + bias.float()                       # packed [32 value | 32 gate] per 64 rows
+            full = full.view(M, N // 64, 2, 32)
+            want = (full[:, :, 0] * F.gelu(full[:, :, 1])).reshape(M, N // 2)
+        else:
+            want = x.float() @ w.float().T + bias.float() + res.float()
+        err = (y.float() - want).abs()
+        tol = 4e-3 + 3e-3 * want.abs()
+        bad = int((err > tol).sum())
+        assert bad == 0, f"plan {(conv, M, N, K, flags, epi, tile, use8, S)}: {bad} off, max err {float(err.max()):.3e}"
+        checked += 1
+        del x, w, y, res, bias, want, err
+    assert checked == len(entries)
+
+
 @pytest.mark.parametrize("B,HW,Cc,G,silu", [(2, 256, 64, 32, 1), (2, 1024, 320, 32, 1), (1, 144, 1280, 32, 0),
                                             (2, 400, 2560, 32, 1), (2, 576, 1920, 32, 1), (2, 100, 960, 32, 0),
                                             (2, 576, 1280, 32, 1), (2, 1229, 1280, 32, 0)])
