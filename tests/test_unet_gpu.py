@@ -97,6 +97,18 @@ def test_conv8_forced(dev, force_gemm8, B, H, W, Cin, Cout, stride, ups):
     test_conv3x3(dev, B, H, W, Cin, Cout, stride, ups)
 
 
+@pytest.mark.parametrize("ni", [2, 3])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 32, 16, 128, 320), (2, 48, 48, 192, 136), (1, 16, 32, 320, 72)])
+def test_conv_halo_forced(dev, ni, B, H, W, Cin, Cout):
+    """Halo-staged conv kernel (conv_halo.hip) forced through the tuning override, incl. ragged feature tiles and image borders."""
+    L, lib = _lib()
+    lib.ctx_gemm_tune(-1, ni)
+    try:
+        test_conv3x3(dev, B, H, W, Cin, Cout, 1, 0)
+    finally:
+        lib.ctx_gemm_tune(-1, -1)
+
+
 @pytest.mark.parametrize("forced", [0, 1])
 @pytest.mark.parametrize("M,C4,K,splitk", [(384, 256, 192, 1), (300, 96, 64, 1), (512, 0, 448, 3), (200, 0, 1024, 5)])
 def test_gemm_geglu_and_splitk(dev, M, C4, K, splitk, forced):

@@ -89,6 +89,10 @@ for s_ in shapes:
         if K % 64 == 0 and (s_[0] == 0 or Cin % 64 == 0) and (K // 64 // S) >= 1:
             t = run(-1, 1, S)
             if t: cands.append((t, -1, 1, S))
+        if s_[0] == 1 and flags == 0 and H % 16 == 0 and W % 16 == 0 and Cin % 64 == 0 and S <= Cin // 64:
+            for u8 in (2, 3):                                   # halo-staged conv, 128 / 64 features per workgroup
+                t = run(-1, u8, S)
+                if t: cands.append((t, -1, u8, S))
     lib.ctx_gemm_tune(-1, -1)
     base = lib.ctx_bench_gemm(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(res_), M, N, K, L.ptr(y), *cb, epi, L.ptr(part), -1, args.iters, L.stream())
     cands.sort()
