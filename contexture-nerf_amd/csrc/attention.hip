@@ -20,9 +20,9 @@
 
 
 struct AttnArgs {
-    const f16 *Q, *K, *Vt;
+    const f16 *Q, *K, *V;
     f16 *O;
-    int Sq, Skv, Sp, heads;
+    int Sq, Skv, heads;
     int q_stride, kv_stride, o_stride;
     float scale_log2e;
 };
@@ -37,13 +37,23 @@ typedef __attribute__((address_space(3))) void *alptr_t;
 
 
 // One 64-key tile of the online-softmax recurrence for this wave's 32 queries (MASK only for the last, ragged tile).
-// V^T arrives with the keys of every 16-group stored as [0-3, 8-11, 4-7, 12-15] (ctx_transpose_v_f16), so the 8 keys a
-// lane half needs for one PV k-step are one 16-byte chunk (the same conflict-free read as the K fragments).  The row sums
-// l = sum_k p ride on the matrix pipe: one extra MFMA per k-step with an all-ones A operand accumulates, in every row
-// of `ls`, the sum of exactly the fp16-rounded P the PV product uses; the VALU is this kernel's critical resource.
+// V stays [key][d] in LDS exactly as it lies in memory (no transpose pass): the PV product's A operand (V^T: row d,
+// 8 keys) comes from two transposing reads ds_read_b64_tr_b16, each a 4-key x 16-d block per 16-lane group: lane
+// (q = (l&15)>>2, p = l&3) points at key row q, d columns 4p..4p+3 and receives d column l&15 of the 4 keys — exactly
+// the keys 4h + (0..3) (then 8 + 4h + (0..3)) that element j of the P fragment holds.  The 16-byte chunk index of the V
+// image is XORed with 4 on key rows 2, 3 (mod 4), which spreads the four rows of a block over all 64 banks.
+// The row sums l = sum_k p ride on the matrix pipe: one extra MFMA per k-step with an all-ones A operand accumulates, in
+// every row of `ls`, the sum of exactly the fp16-rounded P the PV product uses; the VALU is this kernel's critical resource.
+typedef short at_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ f16x4 at_tr16(const f16 *p)
+{
+    at_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4 *)p);
+    return __builtin_bit_cast(f16x4, v);
+}
 template <bool MASK>
 __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 *__restrict__ Vs, int k0, int Skv, int r, int h,
-                                          int swz, float c, const f16x8 (&qf)[4], f32x16 (&o)[2], f32x16 &ls, float &m_run)
+                                          int swz, int vlane, int vfq, float c, const f16x8 (&qf)[4], f32x16 (&o)[2], f32x16 &ls,
+                                          float &m_run)
 {
     f32x16 s[2];
 #pragma unroll
@@ -96,10 +106,12 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
             f16x8 pf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = (f16)s[kb][8 * st + j];
-            const int ch = ((4 * kb + 2 * st + h) ^ swz) * 8;
+            const f16 *vk = Vs + (32 * kb + 16 * st + 4 * h) * 64 + vlane;       // key block of this lane half
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
-                f16x8 vf = *(const f16x8 *)(Vs + (d * 32 + r) * 64 + ch);
+                const int co = ((4 * d) ^ vfq) * 8;                              // d block, swizzled with the lane's key row
+                f16x4 v0 = at_tr16(vk + co), v1 = at_tr16(vk + 8 * 64 + co);
+                f16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[d], 0, 0, 0);
             }
             ls = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, ls, 0, 0, 0);
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
         int lc = (pc ^ ((row >> 1) & 7)) * 8;
         krow[i] = row;
         kp[i] = a.K + ((size_t)b * a.Skv + row) * a.kv_stride + hd * 64 + lc;
-        vp[i] = a.Vt + (((size_t)b * a.heads + hd) * 64 + row) * a.Sp + lc;
+        vp[i] = a.V + ((size_t)b * a.Skv + row) * a.kv_stride + hd * 64 + ((pc ^ (((row >> 1) & 1) << 2)) * 8);
     }
     int issued = 0;
     auto issue = [&](int buf) {
@@ -161,8 +173,9 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((agptr_t)vp[i], (alptr_t)(Vs + (wave + 4 * i) * 512), 16, 0, 0);
-            vp[i] += AT_KB;
+            const f16 *src = (k0 + krow[i] < a.Skv) ? vp[i] : g_attn_zero;
+            __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)(Vs + (wave + 4 * i) * 512), 16, 0, 0);
+            vp[i] += (size_t)AT_KB * a.kv_stride;
         }
         ++issued;
     };
@@ -171,6 +184,9 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
         if (p < ntiles) issue(p);
 
     const int swz = (r >> 1) & 7;
+    // V reads: lane (q = (l&15)>>2, p = l&3, a = (l>>4)&1) -> key row q, d columns 16a + 4p.. of a 32-d block
+    const int vq = (lane & 15) >> 2, vfq = ((vq >> 1) & 1) << 2;
+    const int vlane = vq * 64 + (((2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) ^ 0) * 8) + (lane & 1) * 4;
     const float c = a.scale_log2e;
     // one copy of the tile body in the loop (runtime ring slot): full tiles first, the ragged tile peeled off the end, so
     // the accumulators keep one fixed register block (unrolled / two-variant bodies made hipcc shuffle all 48 of them)
@@ -184,14 +200,14 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
         __builtin_amdgcn_s_barrier();
         if (issued < ntiles) issue(slot == 0 ? AT_NS - 1 : slot - 1);          // the slot tile t-1 used
         const f16 *Ks = ring + slot * (2 * 64 * 64);
-        attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, c, qf, o, ls, m_run);
+        attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
         slot = slot + 1 == AT_NS ? 0 : slot + 1;
     }
     if (nfull < ntiles) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const f16 *Ks = ring + slot * (2 * 64 * 64);
-        attn_tile<true>(Ks, Ks + 64 * 64, nfull * AT_KB, a.Skv, r, h, swz, c, qf, o, ls, m_run);
+        attn_tile<true>(Ks, Ks + 64 * 64, nfull * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
     }
     if (qok) {
         float inv = 1.0f / ls[0];
@@ -208,11 +224,11 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
     }
 }
 
-int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq, int Skv, int Sp, int heads, int q_stride,
+int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, int Skv, int heads, int q_stride,
                        int kv_stride, float scale, f16 *O, int o_stride, hipStream_t s)
 {
     AttnArgs a;
-    a.Q = Q; a.K = K; a.Vt = Vt; a.O = O; a.Sq = Sq; a.Skv = Skv; a.Sp = Sp; a.heads = heads;
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.Sq = Sq; a.Skv = Skv; a.heads = heads;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
     static int ns = -1;
@@ -245,21 +261,19 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq,
 
 extern "C" int64_t ctx_attention_ws_bytes(int32_t B, int32_t Skv, int32_t heads)
 {
-    int Sp = cdiv(Skv, AT_KB) * AT_KB;
-    return (int64_t)B * heads * 64 * Sp * 2;
+    (void)B; (void)Skv; (void)heads;
+    return 256;                                   // no workspace is needed any more (V is consumed untransposed); kept for callers
 }
 
 extern "C" int32_t ctx_attention_f16(const void *Q, const void *K, const void *V, int32_t B, int32_t Sq, int32_t Skv,
                                      int32_t heads, int32_t q_stride, int32_t kv_stride, float scale, void *O,
                                      int32_t o_stride, void *vt_ws, ctx_stream_t stream)
 {
-    CTX_REQUIRE(Q && K && V && O && vt_ws, "attention: null pointer");
+    (void)vt_ws;
+    CTX_REQUIRE(Q && K && V && O, "attention: null pointer");
     CTX_REQUIRE(B > 0 && Sq > 0 && Skv > 0 && heads > 0 && q_stride % 8 == 0 && kv_stride % 8 == 0 && o_stride % 4 == 0 &&
                     q_stride >= heads * 64 && kv_stride >= heads * 64 && o_stride >= heads * 64,
                 "attention: bad strides/sizes (head_dim is fixed at 64)");
-    int Sp = cdiv(Skv, AT_KB) * AT_KB;
-    hipStream_t s = (hipStream_t)stream;
-    ctx_transpose_v_f16((const f16 *)V, B, Skv, kv_stride, heads, Sp, 1, (f16 *)vt_ws, s);
-    return ctx_attention_core((const f16 *)Q, (const f16 *)K, (const f16 *)vt_ws, B, Sq, Skv, Sp, heads, q_stride, kv_stride,
-                              scale, (f16 *)O, o_stride, s);
+    return ctx_attention_core((const f16 *)Q, (const f16 *)K, (const f16 *)V, B, Sq, Skv, heads, q_stride, kv_stride, scale, (f16 *)O,
+                              o_stride, (hipStream_t)stream);
 }

@@ -42,7 +42,7 @@ int ctx_f32_to_f16(const float *x, int64_t n, f16 *y, hipStream_t s);
 int ctx_time_embed_f16(const float *t, int B, int dim, f16 *out, hipStream_t s);
 int ctx_conv_in_f16(const float *x, const f16 *w, const f16 *bias, int B, int Cin, int H, int W, int Cout, f16 *y, hipStream_t s);
 int ctx_conv_out_f16(const f16 *x, const f16 *w, const f16 *bias, int B, int H, int W, int C, int Cout, float *out, hipStream_t s);
-int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *Vt, int B, int Sq, int Skv, int Sp, int heads, int q_stride,
+int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, int Skv, int heads, int q_stride,
                        int kv_stride, float scale, f16 *O, int o_stride, hipStream_t s);
 extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups);
 

@@ -362,12 +362,8 @@ static void op_ln(ctx_unet *u, const f16 *x, size_t g, size_t b, int64_t rows, i
 }
 static void op_attn(ctx_unet *u, const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, int Skv, int heads, int qs, int kvs, f16 *O)
 {
-    int Sp = cdiv(Skv, 64) * 64;
-    f16 *vt = u->allocH((size_t)B * heads * 64 * Sp);
-    note(u, 2, 0);
-    RUN(ctx_transpose_v_f16(V, B, Skv, kvs, heads, Sp, 1, vt, u->s));
     note(u, 1, 4.0 * B * heads * (double)Sq * Skv * 64);
-    RUN(ctx_attention_core(Q, K, vt, B, Sq, Skv, Sp, heads, qs, kvs, 0.125f, O, heads * 64, u->s));
+    RUN(ctx_attention_core(Q, K, V, B, Sq, Skv, heads, qs, kvs, 0.125f, O, heads * 64, u->s));
 }
 
 struct FwdCtx {

@@ -196,7 +196,7 @@ int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const void *beta, in
 int32_t ctx_layernorm_f16(const void *x, const void *gamma, const void *beta, int64_t rows, int32_t C,
                           float eps, void *y, ctx_stream_t stream);
 /* softmax(Q K^T * scale) V; Q[B,Sq,heads*64], K[B,Skv,heads*64], V likewise (f16) -> O[B,Sq,heads*64];
-   row strides in elements.  vt_ws: ctx_attention_ws_bytes() scratch for the transposed V. */
+   row strides in elements.  vt_ws: unused since V is consumed untransposed (ds_read_b64_tr_b16); may be null, ctx_attention_ws_bytes() returns a token size. */
 int64_t ctx_attention_ws_bytes(int32_t B, int32_t Skv, int32_t heads);
 int32_t ctx_attention_f16(const void *Q, const void *K, const void *V, int32_t B, int32_t Sq, int32_t Skv,
                           int32_t heads, int32_t q_stride, int32_t kv_stride, float scale, void *O,
@@ -233,7 +233,8 @@ float ctx_bench_gemm(const void *A, const void *Wt, const void *bias, const void
 void ctx_gemm_tune(int32_t tile, int32_t gemm8);
 
 /* Unit-test support: one 32x32 tile through the MFMA fragment maps the kernels assume.
-   which 0: f16 32x32x16 (A[32][16], Bt[32][16]); 1: f32 32x32x2 (A[32][2], Bt[32][2]); C[32][32] f32. */
+   which 0: f16 32x32x16 (A[32][16], Bt[32][16]); 1: f32 32x32x2 (A[32][2], Bt[32][2]); C[32][32] f32.
+   which 2: the transposing LDS read ds_read_b64_tr_b16 on an f16 tile A[8][32]; C[64 lanes][4] f32 (Bt unused but non-null). */
 int32_t ctx_probe_mfma(int32_t which, const void *A, const void *Bt, float *C, ctx_stream_t stream);
 
 #ifdef __cplusplus

@@ -46,6 +46,20 @@ def test_mfma_lane_maps(dev):
     assert torch.equal(C.cpu(), A2 @ B2.T)
 
 
+def test_tr16_read_map(dev):
+    """The transposing LDS read the attention kernel feeds its PV MFMAs with (V tile kept [key][d], no transpose pass)."""
+    from contexture_nerf_amd import _lib as L
+    lib = L.load()
+    A = torch.arange(8 * 32, dtype=torch.float32).view(8, 32).half()
+    Ad = A.to(dev); Cm = torch.zeros(64, 4, device=dev)
+    L.check(lib.ctx_probe_mfma(2, L.ptr(Ad), L.ptr(Ad), L.ptr(Cm), L.stream()))
+    got = Cm.cpu()
+    for l in range(64):
+        a, h, i = (l >> 4) & 1, l >> 5, l & 15
+        want = A[4 * h:4 * h + 4, 16 * a + i].float()
+        assert torch.equal(got[l], want), (l, got[l], want)
+
+
 @pytest.mark.parametrize("name,B,H,W", [("sphere", 2, 64, 64), ("spot_triangulated", 3, 256, 256),
                                         ("nascar", 7, 200, 200), ("bunny", 1, 97, 131),
                                         ("blub_no_texture", 2, 320, 320), ("env_sphere", 1, 128, 128)])

@@ -27,4 +27,4 @@ for (B, S, Skv, heads) in shapes:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = 4.0 * B * heads * S * Skv * 64
-    print(f"B{B} Sq{S} Skv{Skv} heads{heads}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s (incl. V transpose)")
+    print(f"B{B} Sq{S} Skv{Skv} heads{heads}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s")
