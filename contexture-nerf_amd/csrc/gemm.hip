@@ -466,6 +466,27 @@ void ctx_gemm_plan(GemmArgs &a, bool conv)
                 return;
             }
     }
+    // shapes outside the table: the rules the plan search kept producing (tools/tune_gemm.py, latents 96 / 64 / 32)
+    if (a.K % 64 == 0 && (!conv || a.Cin % 64 == 0)) {
+        const double MN = (double)a.M * a.N;
+        int tile, bm, bn;
+        if (MN >= 5.0e6) { tile = a.epi == 1 ? 10 : (conv ? 12 : 11); bm = 256; bn = 128; }          // 256x128, 8 / 16 waves
+        else if ((MN >= 2.5e6 && a.K >= 960) || (conv && MN >= 1.2e6 && a.K >= 5760)) { tile = 14; bm = 128; bn = 128; }
+        else if (a.epi == 1) { tile = 16; bm = 64; bn = 128; }                                        // GEGLU needs 64-wide wave tiles
+        else { tile = 15; bm = 64; bn = 64; }                                                         // 64x64, 4 waves
+        const int tiles = cdiv(a.M, bm) * cdiv(a.N, bn);
+        int S = 1;
+        if (a.epi == 0 && a.N % 4 == 0) {
+            S = 320 / tiles;                                   // ~1.25 workgroups per CU
+            const int maxS = a.K / 64 / 4;                     // >= 4 stages per slice
+            if (S > maxS) S = maxS;
+            if (S > 12) S = 12;
+            if (S < 1) S = 1;
+        }
+        a.tile = tile; a.splitk = S;
+        a.use8 = (a.epi == 1 && MN >= 1.0e7) ? -1 : 0;        // the 256x256 kernel only where its own heuristic wants it
+        return;
+    }
     a.splitk = ctx_gemm_pick_split(a.M, a.N, a.K, a.epi);
 }
 
