@@ -738,7 +738,7 @@ extern "C" int32_t ctx_get_rays(int32_t H, int32_t W, float fx, float fy, float 
 }
 
 // One wavefront per ray: lane s holds sample s of the current 64-sample chunk.  Transmittance is an
-// exclusive prefix product across lanes (6 shuffle steps), colour/depth/acc are wave sums.  The next chunk's (or next
+// exclusive prefix product across lanes (6 DPP steps), colour/depth/acc are wave sums on the DPP path.  The next chunk's (or next
 // ray's first) loads are issued before the current chunk is reduced, so HBM latency overlaps the shuffle chain.
 __global__ __launch_bounds__(256) void k_composite(const float4 *__restrict__ raw, const float *__restrict__ z,
                                                    const float *__restrict__ rays_d, int64_t R, int S, int white,
@@ -778,21 +778,27 @@ __global__ __launch_bounds__(256) void k_composite(const float4 *__restrict__ ra
         int64_t rn = r; int cn = ch + 1;
         if (cn == nch) { cn = 0; rn = r + nwaves; }
         fetch(rn, cn);
-        float zn = __shfl_down(zv, 1, 64);
-        if (lane == 63) zn = zx;
+        // next sample's depth: wave_shl:1 on the DPP path (lane 63 keeps `old` = the first depth of the following chunk)
+        float zn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, zx), __builtin_bit_cast(int, zv), 0x130, 0xf, 0xf, false));
         float dist = (s + 1 < S) ? (zn - zv) : 1e10f;
         dist = dist * nrm;
         float sigma = q.w > 0.f ? q.w : 0.f;
         float alpha = ok ? 1.0f - __builtin_amdgcn_exp2f(-1.4426950408889634f * sigma * dist) : 0.f;
         float t = ok ? (1.0f - alpha) + 1e-10f : 1.0f;
+        // inclusive prefix product over the 64 lanes on the DPP path (no LDS crossbar): Hillis-Steele inside the 16-lane
+        // rows (row_shr 1, 2, 4, 8; lanes without a source multiply by `old` = 1), then row_bcast 15 / 31 across rows
         float inc = t;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            float up = __shfl_up(inc, o, 64);
-            if (lane >= o) inc = inc * up;
-        }
-        float exc = __shfl_up(inc, 1, 64);
-        if (lane == 0) exc = 1.0f;
+        const int one = 0x3f800000;
+#define CTX_SCAN_STEP(ctrl, rmask) inc = inc * __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(one, __builtin_bit_cast(int, inc), ctrl, rmask, 0xf, false))
+        CTX_SCAN_STEP(0x111, 0xf);
+        CTX_SCAN_STEP(0x112, 0xf);
+        CTX_SCAN_STEP(0x114, 0xf);
+        CTX_SCAN_STEP(0x118, 0xf);
+        CTX_SCAN_STEP(0x142, 0xa);                    // row_bcast:15 into rows 1 and 3
+        CTX_SCAN_STEP(0x143, 0xc);                    // row_bcast:31 into rows 2 and 3
+#undef CTX_SCAN_STEP
+        // exclusive = inclusive shifted right by one lane (wave_shr:1; lane 0 keeps `old` = 1)
+        float exc = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(one, __builtin_bit_cast(int, inc), 0x138, 0xf, 0xf, false));
         float w = alpha * (Tc * exc);
         if (weights && ok) weights[r * S + s] = w;
         c0 += w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * q.x));
@@ -800,9 +806,9 @@ __global__ __launch_bounds__(256) void k_composite(const float4 *__restrict__ ra
         c2 += w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * q.z));
         dep += w * zv;
         a += w;
-        Tc = Tc * __shfl(inc, 63, 64);
+        Tc = Tc * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inc), 63));
         if (ch + 1 == nch) {
-            float s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2), sd = wave_sum(dep), sa = wave_sum(a);
+            float s0 = wave_sum_dpp(c0), s1 = wave_sum_dpp(c1), s2 = wave_sum_dpp(c2), sd = wave_sum_dpp(dep), sa = wave_sum_dpp(a);
             if (lane == 0) {
                 if (white) { s0 += 1.0f - sa; s1 += 1.0f - sa; s2 += 1.0f - sa; }
                 rgb[r * 3 + 0] = s0; rgb[r * 3 + 1] = s1; rgb[r * 3 + 2] = s2;
@@ -822,7 +828,9 @@ extern "C" int32_t ctx_raymarch_composite_fwd(const float *raw, const float *z_v
 {
     CTX_REQUIRE(raw && z_vals && rays_d && rgb && disp && acc && depth && R > 0 && S > 0, "raymarch: bad args");
     int64_t nb = cdiv64(R, 4);
-    if (nb > 16384) nb = 16384;
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("CTX_COMPOSITE_BLOCKS"); cap = e ? atoi(e) : 32768; }
+    if (nb > cap) nb = cap;
     hipLaunchKernelGGL(k_composite, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4 *)raw, z_vals,
                        rays_d, R, S, white_bkgd, rgb, disp, acc, weights, depth);
     CTX_CHECK_LAUNCH("raymarch_composite");
