@@ -26,6 +26,8 @@ SIGNATURES = {
     "ctx_normalize_depth": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ctx_texture_mapping_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctx_texture_mapping_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ctx_texture_pack4": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "ctx_texture_mapping_packed_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctx_view_weights_max": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctx_view_weights_mask": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ctx_face_view_map_ws_bytes": (_i64, [_i32, _i32, _i32]),

@@ -505,6 +505,93 @@ __global__ __launch_bounds__(256) void k_texmap_bwd(const float *__restrict__ go
     }
 }
 
+// Texel-interleaved variant for C <= 4 and one shared texture: [C,T,T] is repacked once into [T,T,4] (16 bytes per
+// texel) so a bilinear tap is ONE 16-byte gather instead of C 4-byte gathers; the per-channel arithmetic and its order are
+// those of k_texmap_fwd (results are bit-identical).
+__global__ __launch_bounds__(256) void k_tex_pack4(const float *__restrict__ tex, int C, int T, float4 *__restrict__ packed)
+{
+    const int64_t n = (int64_t)T * T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x = tex[i];
+        if (C > 1) v.y = tex[n + i];
+        if (C > 2) v.z = tex[2 * n + i];
+        if (C > 3) v.w = tex[3 * n + i];
+        packed[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_texmap_fwd4(const float *__restrict__ uv, const float4 *__restrict__ tex, int64_t HW, int C,
+                                                     int T, int mode, const int64_t *__restrict__ mask_idx, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        const size_t pix = (size_t)b * HW + i;
+        float2 q = *(const float2 *)(uv + pix * 2);
+        float ix = src_index(q.x * 2.0f - 1.0f, T), iy = src_index((1.0f - q.y) * 2.0f - 1.0f, T);
+        float msk = 1.0f;
+        if (mask_idx) msk = mask_idx[pix] > -1 ? 1.0f : 0.0f;
+        float r[4];
+        if (mode == 1) {
+            int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+            bool in = xn >= 0 && xn < T && yn >= 0 && yn < T;
+            float4 t = in ? tex[(size_t)yn * T + xn] : make_float4(0.f, 0.f, 0.f, 0.f);
+            r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+        } else {
+            float fx = floorf(ix), fy = floorf(iy);
+            int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+            float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+            float wne = (ix - (float)x0) * ((float)y1 - iy);
+            float wsw = ((float)x1 - ix) * (iy - (float)y0);
+            float wse = (ix - (float)x0) * (iy - (float)y0);
+            bool bx0 = x0 >= 0 && x0 < T, bx1 = x1 >= 0 && x1 < T, by0 = y0 >= 0 && y0 < T, by1 = y1 >= 0 && y1 < T;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            // unconditional (clamped) gathers, then the same guarded accumulation order as the planar kernel
+            float4 tnw = tex[(size_t)min(max(y0, 0), T - 1) * T + min(max(x0, 0), T - 1)];
+            float4 tne = tex[(size_t)min(max(y0, 0), T - 1) * T + min(max(x1, 0), T - 1)];
+            float4 tsw = tex[(size_t)min(max(y1, 0), T - 1) * T + min(max(x0, 0), T - 1)];
+            float4 tse = tex[(size_t)min(max(y1, 0), T - 1) * T + min(max(x1, 0), T - 1)];
+            (void)z4;
+            const float a_nw[4] = {tnw.x, tnw.y, tnw.z, tnw.w}, a_ne[4] = {tne.x, tne.y, tne.z, tne.w};
+            const float a_sw[4] = {tsw.x, tsw.y, tsw.z, tsw.w}, a_se[4] = {tse.x, tse.y, tse.z, tse.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = 0.0f;
+                if (bx0 && by0) acc = acc + a_nw[c] * wnw;
+                if (bx1 && by0) acc = acc + a_ne[c] * wne;
+                if (bx0 && by1) acc = acc + a_sw[c] * wsw;
+                if (bx1 && by1) acc = acc + a_se[c] * wse;
+                r[c] = acc;
+            }
+        }
+        float *o = out + pix * C;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) o[c] = mask_idx ? r[c] * msk : r[c];
+    }
+}
+
+extern "C" int32_t ctx_texture_pack4(const float *tex, int32_t C, int32_t T, float *packed, ctx_stream_t stream)
+{
+    CTX_REQUIRE(tex && packed && C >= 1 && C <= 4 && T > 0, "texture_pack4: bad args C=%d T=%d", C, T);
+    int nb = min(cdiv(T * T, 256), 4096);
+    hipLaunchKernelGGL(k_tex_pack4, dim3(nb), dim3(256), 0, (hipStream_t)stream, tex, C, T, (float4 *)packed);
+    CTX_CHECK_LAUNCH("texture_pack4");
+    return CTX_OK;
+}
+
+extern "C" int32_t ctx_texture_mapping_packed_fwd(const float *uv, const float *packed, int32_t B, int32_t HW, int32_t C, int32_t T,
+                                                  int32_t mode, const int64_t *mask_idx, float *out, ctx_stream_t stream)
+{
+    CTX_REQUIRE(uv && packed && out, "texture_mapping_packed: null pointer");
+    CTX_REQUIRE(B > 0 && HW > 0 && C >= 1 && C <= 4 && T > 0 && (mode == 0 || mode == 1), "texture_mapping_packed: bad args");
+    int nb = min(cdiv(HW, 256), 4096);
+    hipLaunchKernelGGL(k_texmap_fwd4, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, uv, (const float4 *)packed, (int64_t)HW, C, T, mode,
+                       mask_idx, out);
+    CTX_CHECK_LAUNCH("texture_mapping_packed_fwd");
+    return CTX_OK;
+}
+
 extern "C" int32_t ctx_texture_mapping_fwd(const float *uv, const float *tex, int32_t B, int32_t HW, int32_t C,
                                            int32_t T, int32_t Bt, int32_t mode, const int64_t *mask_idx, float *out,
                                            ctx_stream_t stream)

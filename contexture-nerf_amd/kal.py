@@ -122,9 +122,19 @@ class _TextureMapping(torch.autograd.Function):
             tex_c, Bt_eff = tex.contiguous(), Bt
         uvc = L.f32c(uv)
         out = torch.empty(B, H, W, Cc, device=uv.device)
-        L.check(lib.ctx_texture_mapping_fwd(L.ptr(uvc, torch.float32, "texture_coordinates"),
-                                            L.ptr(tex_c, torch.float32, "texture_maps"), B, H * W, Cc, T, Bt_eff,
-                                            {'bilinear': 0, 'nearest': 1}[mode], L.ptr(mask_idx), L.ptr(out), L.stream()))
+        m = {'bilinear': 0, 'nearest': 1}[mode]
+        if Bt_eff == 1 and Cc <= 4 and B * H * W >= 4 * T * T:
+            # one shared texture sampled by many more pixels than it has texels: interleave the channels once (16 B per
+            # texel), then every bilinear tap is one gather (bit-identical results)
+            packed = torch.empty(T, T, 4, device=uv.device)
+            L.check(lib.ctx_texture_pack4(L.ptr(tex_c.float() if tex_c.dtype != torch.float32 else tex_c, torch.float32, "texture_maps"),
+                                          Cc, T, L.ptr(packed), L.stream()))
+            L.check(lib.ctx_texture_mapping_packed_fwd(L.ptr(uvc, torch.float32, "texture_coordinates"), L.ptr(packed), B, H * W, Cc, T, m,
+                                                       L.ptr(mask_idx), L.ptr(out), L.stream()))
+        else:
+            L.check(lib.ctx_texture_mapping_fwd(L.ptr(uvc, torch.float32, "texture_coordinates"),
+                                                L.ptr(tex_c, torch.float32, "texture_maps"), B, H * W, Cc, T, Bt_eff,
+                                                m, L.ptr(mask_idx), L.ptr(out), L.stream()))
         ctx.save_for_backward(uvc, mask_idx if mask_idx is not None else torch.empty(0))
         ctx.meta = (B, H * W, Cc, T, Bt, Bt_eff, mode, tex.shape, mask_idx is not None)
         return out

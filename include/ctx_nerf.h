@@ -79,6 +79,13 @@ int32_t ctx_texture_mapping_bwd(const float *grad_out, const float *uv, int32_t 
                                 int32_t C, int32_t T, const int64_t *mask_idx, float *grad_tex,
                                 ctx_stream_t stream);
 
+/* Texel-interleaved forward for C <= 4 and one texture shared by the batch (the reference's texture_img.expand(B, ...),
+   render.py:133-135): ctx_texture_pack4 repacks [C,T,T] into [T,T,4] once, ctx_texture_mapping_packed_fwd then gathers one
+   16-byte texel per bilinear tap.  Results are bit-identical to ctx_texture_mapping_fwd. */
+int32_t ctx_texture_pack4(const float *tex, int32_t C, int32_t T, float *packed, ctx_stream_t stream);
+int32_t ctx_texture_mapping_packed_fwd(const float *uv, const float *packed, int32_t B, int32_t HW, int32_t C, int32_t T,
+                                       int32_t mode, const int64_t *mask_idx, float *out, ctx_stream_t stream);
+
 /* ---- view weights: torch_scatter.scatter_max seam (src/training/trainer.py:213-249) ------- */
 /* phase 0: max_z[f] = max(max_z[f], fnz[b,f]) over pixels of the B local views showing f.
    Caller pre-fills max_z with -inf; between the phases a multi-GPU caller all-reduces(MAX). */

@@ -83,4 +83,4 @@ def test_size_queries():
     assert lib.ctx_rasterize_ws_bytes(1200, 1200, 7, 7500) > 7 * 361 * 7500 * 4
     assert lib.ctx_uvmlp_packed_bytes(8, 256, 42, 3, 4) > 483075 * 4
     assert lib.ctx_uvmlp_packed_bytes(8, 100, 42, 3, 4) == -1
-    assert lib.ctx_attention_ws_bytes(2, 77, 5) == 2 * 5 * 64 * 128 * 2
+    assert lib.ctx_attention_ws_bytes(2, 77, 5) == 256          # V is consumed untransposed: token size only

@@ -144,6 +144,13 @@ def test_texture_mapping_fwd_bwd(dev):
         ref = torch.nn.functional.grid_sample(tex.expand(3, -1, -1, -1), torch.stack([uv[..., 0], 1 - uv[..., 1]], -1) * 2 - 1,
                                               mode=mode, align_corners=False, padding_mode='border').permute(0, 2, 3, 1)
         np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    # few pixels per texel -> the planar kernel; many -> the texel-interleaved one (3x70x90 above); both bit-exact, also masked
+    uv2 = torch.rand(1, 30, 40, 2, generator=g) * 1.1 - 0.05
+    for uvx in (uv2, uv):
+        mi = (torch.rand(uvx.shape[:3], generator=g) > 0.3).long() * 5 - 1
+        o = og.texture_mapping(uvx.numpy(), tex.numpy(), 'bilinear') * (mi.numpy() > -1)[..., None]
+        out = kal.render.mesh.texture_mapping(uvx.to(dev), tex.to(dev).expand(uvx.shape[0], -1, -1, -1), mask_idx=mi.to(dev))
+        assert np.array_equal(out.cpu().numpy(), o.astype(np.float32))
     # backward (float atomics: order-dependent rounding -> tolerance, stated here: 1e-5 abs on O(10) sums)
     texd = tex.to(dev).requires_grad_(True)
     y = kal.render.mesh.texture_mapping(uv.to(dev), texd.expand(3, -1, -1, -1))
