@@ -544,33 +544,58 @@ int ctx_conv_in_f16(const float *x, const f16 *w, const f16 *bias, int B, int Ci
 }
 
 // conv_out: x [B,H,W,C] f16 (already GN+SiLU'd) -> out [B,Cout,H,W] f32 NCHW, Cout <= 4, 3x3 pad 1.
-// w packed [Cout][3][3][C] f16.  One wave per output pixel: lanes split C in 16-byte chunks.
+// w packed [Cout][3][3][C] f16, staged in LDS once per block.  One wave per output pixel: the 9 taps x C/8 16-byte chunks
+// of the pixel's neighbourhood are one flat item list dealt over the 64 lanes (all lanes busy for any C), every load of a
+// lane issued (unconditionally, clamped) before the first use; the Cout sums are DPP wave reductions.
+template <int NU>
 __global__ __launch_bounds__(256) void k_conv_out(const f16 *__restrict__ x, const f16 *__restrict__ w,
                                                   const f16 *__restrict__ bias, int B, int H, int W, int C, int Cout,
                                                   float *__restrict__ out)
 {
+    extern __shared__ __attribute__((aligned(16))) f16 s_cw[];     // [Cout][9][C]
+    const int nwt = Cout * 9 * C;
+    for (int i = threadIdx.x * 8; i < nwt; i += 256 * 8) *(f16x8 *)(s_cw + i) = *(const f16x8 *)(w + i);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
+    const int c8n = C / 8, nitems = 9 * c8n;
     const int64_t npix = (int64_t)B * H * W;
-    for (int64_t pix = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; pix < npix; pix += ((int64_t)gridDim.x * 256) >> 6) {
-        int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
-        int oy = p / W, ox = p % W;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int tap = 0; tap < 9; ++tap) {
-            int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-            const f16 *xr = x + (((size_t)b * H + iy) * W + ix) * C;
-            for (int c = lane * 8; c < C; c += 512) {
-                f16x8 xv = *(const f16x8 *)(xr + c);
-                for (int o = 0; o < Cout; ++o) {
-                    f16x8 wv = *(const f16x8 *)(w + ((size_t)o * 9 + tap) * C + c);
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    int itap[NU], ic[NU];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[o] += (float)xv[j] * (float)wv[j];
+    for (int u = 0; u < NU; ++u) {
+        const int i = min(lane + 64 * u, nitems - 1);
+        itap[u] = i / c8n; ic[u] = (i - itap[u] * c8n) * 8;
+    }
+    for (int64_t pix = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; pix < npix; pix += ((int64_t)gridDim.x * 256) >> 6) {
+        const int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
+        const int oy = p / W, ox = p % W;
+        f16x8 xv[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int iy = oy + itap[u] / 3 - 1, ix = ox + itap[u] % 3 - 1;
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            xv[u] = *(const f16x8 *)(x + (((size_t)b * H + cy) * W + cx) * C + ic[u]);
+            if (lane + 64 * u >= nitems || iy != cy || ix != cx) xv[u] = zero8;
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const f16 *wr = s_cw + itap[u] * C + ic[u];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o < Cout) {
+                    f16x8 wv = *(const f16x8 *)(wr + o * 9 * C);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[o] += (float)xv[u][j] * (float)wv[j];
                 }
             }
         }
-        for (int o = 0; o < Cout; ++o) {
-            float v = wave_sum(acc[o]);
-            if (lane == 0) out[(((size_t)b * Cout + o) * H + oy) * W + ox] = v + (float)bias[o];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o < Cout) {
+                float v = wave_sum_dpp(acc[o]);
+                if (lane == 0) out[(((size_t)b * Cout + o) * H + oy) * W + ox] = v + (float)bias[o];
+            }
         }
     }
 }
@@ -578,7 +603,15 @@ int ctx_conv_out_f16(const f16 *x, const f16 *w, const f16 *bias, int B, int H, 
 {
     int64_t nb = cdiv64((int64_t)B * H * W, 4);
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(k_conv_out, dim3((unsigned)nb), dim3(256), 0, s, x, w, bias, B, H, W, C, Cout, out);
+    const int nitems = 9 * (C / 8);
+    const size_t lds = (size_t)Cout * 9 * C * sizeof(f16);
+    if (Cout > 4 || C % 8 != 0 || nitems > 64 * 12 || lds > 64 * 1024) {
+        ctx_set_error("conv_out: unsupported C=%d Cout=%d", C, Cout);
+        return CTX_E_ARG;
+    }
+    if (nitems <= 64 * 3) hipLaunchKernelGGL(k_conv_out<3>, dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, B, H, W, C, Cout, out);
+    else if (nitems <= 64 * 6) hipLaunchKernelGGL(k_conv_out<6>, dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, B, H, W, C, Cout, out);
+    else hipLaunchKernelGGL(k_conv_out<12>, dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, B, H, W, C, Cout, out);
     return CTX_OK;
 }
 
