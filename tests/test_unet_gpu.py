@@ -97,6 +97,20 @@ def test_conv8_forced(dev, force_gemm8, B, H, W, Cin, Cout, stride, ups):
     test_conv3x3(dev, B, H, W, Cin, Cout, stride, ups)
 
 
+@pytest.mark.parametrize("tile", list(range(23)))
+def test_every_tile_form(dev, tile):
+    """Each tile form of gemm.hip forced through the tuning override: GEMM with ragged M / N and a convolution."""
+    L, lib = _lib()
+    lib.ctx_gemm_tune(tile, 0)
+    try:
+        test_gemm(dev, 300, 320, 320)
+        test_gemm(dev, 1000, 200, 128)
+        test_conv3x3(dev, 2, 16, 12, 64, 128, 1, 0)
+        test_conv3x3(dev, 1, 9, 13, 128, 320, 2, 0)
+    finally:
+        lib.ctx_gemm_tune(-1, -1)
+
+
 @pytest.mark.parametrize("ni", [2, 3])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 32, 16, 128, 320), (2, 48, 48, 192, 136), (1, 16, 32, 320, 72)])
 def test_conv_halo_forced(dev, ni, B, H, W, Cin, Cout):
