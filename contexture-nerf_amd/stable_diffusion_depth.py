@@ -68,43 +68,57 @@ class StableDiffusion:
             imgs = self.vae.decode(latents).sample
         return (imgs / 2 + 0.5).clamp(0, 1)
 
-    def img2img_step(self, text_embeddings, inputs, original_depth_mask, guidance_scale=100, strength=0.5,
-                     num_inference_steps=50, update_mask=None, latent_mode=False, fixed_seed=None, intermediate_vis=False,
-                     view_dir=None, front_image=None, phi=None, theta=None, condition_guidance_scales=None, image_size=512):
-        intermediate_results = []
+    def _new_scheduler(self):
+        return PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                             num_train_timesteps=self.num_train_timesteps, steps_offset=1, skip_prk_steps=True)
 
-        def sample(latents, depth_mask, strength, num_inference_steps, update_mask=None, masked_latents=None):
-            self.scheduler.set_timesteps(num_inference_steps)
-            shape = (text_embeddings.shape[0] // 2, self.unet.in_channels - 1, depth_mask.shape[2], depth_mask.shape[3])
+    class _Denoise:
+        """The inner `sample` loop of img2img_step (stable_diffusion_depth.py:297-516) as a resumable job: construction does
+        what precedes the loop, advance() is one loop body (CFG-batched UNet evaluation + fused CFG / PLMS update)."""
+
+        def __init__(self, sd, unet, scheduler, text_embeddings, latents, depth_mask, strength, num_inference_steps, update_mask,
+                     fixed_seed, guidance_scale):
+            self.sd, self.unet, self.scheduler = sd, unet, scheduler
+            self.text_embeddings, self.guidance_scale = text_embeddings, guidance_scale
+            scheduler.set_timesteps(num_inference_steps)
+            shape = (text_embeddings.shape[0] // 2, unet.in_channels - 1, depth_mask.shape[2], depth_mask.shape[3])
             if latents is None:
-                latents = torch.randn(shape, device=self.device)
-                timesteps = self.scheduler.timesteps
+                latents = torch.randn(shape, device=sd.device)
+                timesteps = scheduler.timesteps
             else:
-                timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength)
+                init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+                timesteps = scheduler.timesteps[max(num_inference_steps - init_timestep, 0):]
                 latent_timestep = timesteps[:1]
                 if fixed_seed is not None:
                     seed_everything(fixed_seed)
                 noise = torch.randn_like(latents)
                 if update_mask is not None:
-                    latents = torch.randn(shape, device=self.device)      # gt_latents are never blended (blend commented out, :382)
+                    latents = torch.randn(shape, device=sd.device)        # gt_latents are never blended (blend commented out, :382)
                 else:
-                    latents = self.scheduler.add_noise(latents, noise, latent_timestep)
-            depth2 = torch.cat([depth_mask] * 2)
-            for i, t in enumerate(timesteps):
-                latent_model_input = torch.cat([latents] * 2)
-                latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
-                x = torch.cat([latent_model_input, depth2], dim=1)
-                noise_pred = self.unet(x, float(t), encoder_hidden_states=text_embeddings)['sample']
-                latents = self.scheduler.step_cfg(noise_pred, guidance_scale, int(t), latents)['prev_sample']
-            return latents
+                    latents = scheduler.add_noise(latents, noise, latent_timestep)
+            self.latents, self.timesteps, self.i = latents, timesteps, 0
+            self.depth2 = torch.cat([depth_mask] * 2)
 
+        def done(self):
+            return self.i >= len(self.timesteps)
+
+        def advance(self):
+            t = self.timesteps[self.i]
+            latent_model_input = torch.cat([self.latents] * 2)
+            latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+            x = torch.cat([latent_model_input, self.depth2], dim=1)
+            noise_pred = self.unet(x, float(t), encoder_hidden_states=self.text_embeddings)['sample']
+            self.latents = self.scheduler.step_cfg(noise_pred, self.guidance_scale, int(t), self.latents)['prev_sample']
+            self.i += 1
+
+    def _prepare(self, inputs, original_depth_mask, update_mask, latent_mode, image_size):
         depth_mask = F.interpolate(original_depth_mask, size=(image_size // 8, image_size // 8), mode='bicubic', align_corners=False)
         if inputs is None:
             latents = None
         elif latent_mode:
             latents = inputs
         elif not hasattr(self.vae, 'encode'):
-            # the encoded render only matters when update_mask is None (it is discarded otherwise, see sample()):
+            # the encoded render only matters when update_mask is None (it is discarded otherwise, see _Denoise):
             # the reference's live call always passes update_mask, so a zero latent of the right shape is equivalent
             latents = torch.zeros(inputs.shape[0], self.unet.in_channels - 1, image_size // 8, image_size // 8, device=self.device)
         else:
@@ -113,10 +127,61 @@ class StableDiffusion:
         if update_mask is not None:
             update_mask = F.interpolate(update_mask, (image_size // 8, image_size // 8), mode='nearest')
         depth_mask = 2.0 * (depth_mask - depth_mask.min()) / (depth_mask.max() - depth_mask.min()) - 1.0
+        return latents, depth_mask, update_mask
+
+    def img2img_step(self, text_embeddings, inputs, original_depth_mask, guidance_scale=100, strength=0.5,
+                     num_inference_steps=50, update_mask=None, latent_mode=False, fixed_seed=None, intermediate_vis=False,
+                     view_dir=None, front_image=None, phi=None, theta=None, condition_guidance_scales=None, image_size=512):
+        intermediate_results = []
+        latents, depth_mask, update_mask = self._prepare(inputs, original_depth_mask, update_mask, latent_mode, image_size)
         with torch.no_grad():
-            target_latents = sample(latents, depth_mask, strength=strength, num_inference_steps=num_inference_steps,
-                                    update_mask=update_mask)
+            job = StableDiffusion._Denoise(self, self.unet, self.scheduler, text_embeddings, latents, depth_mask, strength,
+                                           num_inference_steps, update_mask, fixed_seed, guidance_scale)
+            while not job.done():
+                job.advance()
+            target_latents = job.latents
             target_rgb = self.decode_latents(target_latents)
         if latent_mode:
             return target_rgb, target_latents
         return target_rgb, intermediate_results
+
+    def img2img_step_pair(self, calls):
+        """Two img2img_step calls (two views of one mesh) with their denoise loops in flight together: two HIP streams, two
+        engines over ONE weight blob (UNet2DConditionModel.clone_shared), two schedulers.  `calls` = two dicts of
+        img2img_step keyword arguments.  Each result is what img2img_step(**call) returns on its own (same seeds, same
+        deterministic kernels); the pair finishes ~1.25x sooner because the deep UNet levels do not fill the chip."""
+        assert len(calls) == 2
+        if getattr(self, '_unet2', None) is None:
+            self._unet2 = self.unet.clone_shared()
+        main = torch.cuda.current_stream(self.device)
+        streams = getattr(self, '_pair_streams', None)
+        if streams is None:
+            streams = self._pair_streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+        jobs, metas = [], []
+        with torch.no_grad():
+            for k, kw in enumerate(calls):
+                kw = dict(kw)
+                image_size = kw.get('image_size', 512)
+                latent_mode = kw.get('latent_mode', False)
+                latents, depth_mask, update_mask = self._prepare(kw['inputs'], kw['original_depth_mask'], kw.get('update_mask'),
+                                                                 latent_mode, image_size)
+                jobs.append(StableDiffusion._Denoise(self, self.unet if k == 0 else self._unet2, self._new_scheduler(),
+                                                     kw['text_embeddings'], latents, depth_mask, kw.get('strength', 0.5),
+                                                     kw.get('num_inference_steps', 50), update_mask, kw.get('fixed_seed'),
+                                                     kw.get('guidance_scale', 100)))
+                metas.append(latent_mode)
+            for st in streams:
+                st.wait_stream(main)
+            while not (jobs[0].done() and jobs[1].done()):
+                for k in range(2):
+                    if not jobs[k].done():
+                        with torch.cuda.stream(streams[k]):
+                            jobs[k].advance()
+            for st in streams:
+                main.wait_stream(st)
+            outs = []
+            for k in range(2):
+                jobs[k].latents.record_stream(main)
+                rgb = self.decode_latents(jobs[k].latents)
+                outs.append((rgb, jobs[k].latents) if metas[k] else (rgb, []))
+        return outs

@@ -59,7 +59,8 @@ class ConTEXTure:
         return self.view_weights
 
     # ---- trainer.py:971-1117 ---------------------------------------------------------------------------------
-    def paint_viewpoint(self, data, should_project_back=False, image_size=None, num_inference_steps=None):
+    def _paint_prepare(self, data, image_size=None, num_inference_steps=None):
+        """Everything of paint_viewpoint up to the diffusion call: render, crop box; returns (img2img kwargs, context)."""
         theta, phi, radius = data['theta'], data['phi'], data['radius']
         phi = phi - math.radians(self.cfg.render.front_offset)
         phi = float(phi + 2 * math.pi if phi < 0 else phi)
@@ -68,7 +69,6 @@ class ConTEXTure:
             if not self.cfg.guide.use_background_color else torch.tensor([0.0, 0.8, 0.0], device=self.device)
         outputs = self.mesh_model.render(theta=theta, phi=phi, radius=radius, background=background)
         render_cache = outputs['render_cache']
-        rgb_render_raw = outputs['image']
         depth_render = outputs['depth']
         outputs = self.mesh_model.render(background=background, render_cache=render_cache, use_median=self.paint_step > 1)
         rgb_render = outputs['image']
@@ -78,17 +78,39 @@ class ConTEXTure:
         crop = lambda x: x[:, :, min_h:max_h, min_w:max_w]
         cropped_rgb_render, cropped_depth_render, cropped_update_mask = crop(rgb_render), crop(depth_render), crop(object_mask)
         text_z = self.text_z if self.text_z is not None else self.diffusion.get_text_embeds([self.cfg.guide.text])
-        cropped_rgb_output, _ = self.diffusion.img2img_step(
-            text_z, cropped_rgb_render.detach(), cropped_depth_render.detach(), guidance_scale=self.cfg.guide.guidance_scale,
-            strength=1.0, update_mask=cropped_update_mask, fixed_seed=self.cfg.optim.seed, intermediate_vis=False,
-            num_inference_steps=num_inference_steps or self.cfg.guide.num_inference_steps,
-            image_size=image_size or self.cfg.guide.sd_image_size)
-        cropped_rgb_output = F.interpolate(cropped_rgb_output, (cropped_rgb_render.shape[2], cropped_rgb_render.shape[3]),
-                                           mode='bilinear', align_corners=False)
-        rgb_output = rgb_render.clone()
+        kw = dict(text_embeddings=text_z, inputs=cropped_rgb_render.detach(), original_depth_mask=cropped_depth_render.detach(),
+                  guidance_scale=self.cfg.guide.guidance_scale, strength=1.0, update_mask=cropped_update_mask,
+                  fixed_seed=self.cfg.optim.seed, intermediate_vis=False,
+                  num_inference_steps=num_inference_steps or self.cfg.guide.num_inference_steps,
+                  image_size=image_size or self.cfg.guide.sd_image_size)
+        ctx = dict(render_cache=render_cache, z_normals=z_normals, rgb_render=rgb_render, object_mask=object_mask,
+                   box=(min_h, min_w, max_h, max_w), crop_hw=(cropped_rgb_render.shape[2], cropped_rgb_render.shape[3]))
+        return kw, ctx
+
+    def _paint_finish(self, ctx, cropped_rgb_output):
+        cropped_rgb_output = F.interpolate(cropped_rgb_output, ctx['crop_hw'], mode='bilinear', align_corners=False)
+        min_h, min_w, max_h, max_w = ctx['box']
+        rgb_output = ctx['rgb_render'].clone()
         rgb_output[:, :, min_h:max_h, min_w:max_w] = cropped_rgb_output
-        self._last = dict(render_cache=render_cache, z_normals=z_normals)
-        return rgb_output, object_mask
+        self._last = dict(render_cache=ctx['render_cache'], z_normals=ctx['z_normals'])
+        return rgb_output, ctx['object_mask']
+
+    def paint_viewpoint(self, data, should_project_back=False, image_size=None, num_inference_steps=None):
+        kw, ctx = self._paint_prepare(data, image_size, num_inference_steps)
+        te = kw.pop('text_embeddings'); inp = kw.pop('inputs'); dm = kw.pop('original_depth_mask')
+        cropped_rgb_output, _ = self.diffusion.img2img_step(te, inp, dm, **kw)
+        return self._paint_finish(ctx, cropped_rgb_output)
+
+    def paint_viewpoints_pair(self, data_a, data_b, image_size=None, num_inference_steps=None):
+        """Two views painted with their denoise loops in flight together (StableDiffusion.img2img_step_pair): same result per
+        view as paint_viewpoint, ~1.25x sooner per pair.  Returns [(rgb_output, object_mask, last)] for the two views."""
+        preps = [self._paint_prepare(d, image_size, num_inference_steps) for d in (data_a, data_b)]
+        outs = self.diffusion.img2img_step_pair([p[0] for p in preps])
+        res = []
+        for (kw, ctx), (rgb, _) in zip(preps, outs):
+            rgb_output, mask = self._paint_finish(ctx, rgb)
+            res.append((rgb_output, mask, self._last))
+        return res
 
     # ---- north_star "UV back-projection" (absent in the reference, SURVEY R6 / §8f n1) ----------------------------
     def project_back_scatter(self, render_cache, rgb_output, weight_mask):
@@ -117,8 +139,18 @@ class ConTEXTure:
         else:                                           # idle rank still joins the collectives
             F_ = self.mesh_model.mesh.faces.shape[0]
             D.all_reduce_max_(torch.full((F_,), float('-inf'), device=self.device), self.group)
-        for j, k in enumerate(mine):
-            rgb, obj_mask = self.paint_viewpoint(self.train_views[k], image_size=image_size, num_inference_steps=num_inference_steps)
-            contrib += self.project_back_scatter(self._last['render_cache'], rgb, masks[j:j + 1] & (obj_mask > 0))
+        j = 0
+        pair = getattr(self.cfg.optim, 'views_in_flight', 2) >= 2 and hasattr(self.diffusion, 'img2img_step_pair')
+        while j < len(mine):
+            if pair and j + 1 < len(mine):           # a rank that owns several views paints them two at a time
+                res = self.paint_viewpoints_pair(self.train_views[mine[j]], self.train_views[mine[j + 1]], image_size=image_size,
+                                                 num_inference_steps=num_inference_steps)
+                for o, (rgb, obj_mask, last) in enumerate(res):
+                    contrib += self.project_back_scatter(last['render_cache'], rgb, masks[j + o:j + o + 1] & (obj_mask > 0))
+                j += 2
+            else:
+                rgb, obj_mask = self.paint_viewpoint(self.train_views[mine[j]], image_size=image_size, num_inference_steps=num_inference_steps)
+                contrib += self.project_back_scatter(self._last['render_cache'], rgb, masks[j:j + 1] & (obj_mask > 0))
+                j += 1
         atlas, coverage = D.merge_atlas(contrib, self.group)
         return atlas, coverage

@@ -100,7 +100,14 @@ def test_trainer_view_weights_paint_and_atlas(dev, meshes):
     # one painted view and the full sharded loop (world 1)
     rgb, obj = tr.paint_viewpoint(tr.train_views[0])
     assert rgb.shape == (1, 3, 160, 160) and obj.shape == (1, 1, 160, 160) and torch.isfinite(rgb).all()
+    # two views in flight (two streams, two engines over one weight blob) == the same two views one after the other
+    rgb1, obj1 = tr.paint_viewpoint(tr.train_views[1])
+    pair = tr.paint_viewpoints_pair(tr.train_views[0], tr.train_views[1])
+    assert torch.equal(pair[0][0], rgb) and torch.equal(pair[1][0], rgb1) and torch.equal(pair[1][1], obj1)
     atlas, cov = tr.paint()
     assert atlas.shape == (3, 128, 128) and torch.isfinite(atlas).all()
+    tr.cfg.optim.views_in_flight = 1                                    # serial loop gives the same atlas
+    atlas1, _ = tr.paint()
+    assert torch.allclose(atlas1, atlas, rtol=1e-5, atol=1e-6)          # float-atomic scatter order only
     assert 0.05 < float((cov > 0).float().mean()) <= 1.0
     assert float(atlas.min()) >= 0 and float(atlas.max()) <= 1.0 + 1e-5
