@@ -491,42 +491,37 @@ int ctx_time_embed_f16(const float *t, int B, int dim, f16 *out, hipStream_t s)
 // conv_in: sample [B,Cin,H,W] f32 NCHW (Cin <= 8) -> y [B,H,W,Cout] f16, 3x3 pad 1.  w packed [Cout][3][3][8] f16.
 // One pixel per lane: its 9 x Cin inputs live in registers; the weights of this block's slice of output channels
 // sit in LDS and are read as wave-wide broadcasts; grid.y splits the output channels.
-// conv_in: x [B,Cin,H,W] f32 NCHW (Cin <= 8) -> y [B,H,W,Cout] f16 NHWC, 3x3 pad 1; w packed [Cout][9][8] f16 (Cin padded to 8).
-// A thread owns (pixel, 8 output channels), consecutive threads walk the channels of one pixel, so a pixel's Cout*2 bytes
-// leave as one contiguous run; the whole weight matrix sits in LDS.
+#define CI_SPLIT 4
 __global__ __launch_bounds__(256) void k_conv_in(const float *__restrict__ x, const f16 *__restrict__ w,
                                                  const f16 *__restrict__ bias, int B, int Cin, int H, int W, int Cout,
                                                  f16 *__restrict__ y)
 {
-    extern __shared__ __attribute__((aligned(16))) f16 s_w[];     // [this block row's output channels][72]
-    // blockIdx.y owns a slice of the output channels (the weights of one slice fit LDS)
-    const int o8all = Cout / 8, o8per = (o8all + gridDim.y - 1) / gridDim.y;
-    const int o8beg = blockIdx.y * o8per, o8n = min(o8all, o8beg + o8per) - o8beg;
-    const int nw = o8n * 8 * 72;
-    for (int i = threadIdx.x * 8; i < nw; i += 256 * 8) *(f16x8 *)(s_w + i) = *(const f16x8 *)(w + (size_t)o8beg * 8 * 72 + i);
+    extern __shared__ __attribute__((aligned(16))) f16 s_w[];     // [o_per][72]
+    const int o8n = Cout / 8;
+    const int o8_per = (o8n + CI_SPLIT - 1) / CI_SPLIT;
+    const int o8_0 = blockIdx.y * o8_per, o8_1 = min(o8n, o8_0 + o8_per);
+    const int nw = (o8_1 - o8_0) * 8 * 72;
+    for (int i = threadIdx.x; i < nw; i += 256) s_w[i] = w[(size_t)o8_0 * 8 * 72 + i];
     __syncthreads();
-    const int64_t total = (int64_t)B * H * W * o8n;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t pix = i / o8n;
-        const int o8l = (int)(i - pix * o8n), o8 = o8beg + o8l;
-        const int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
-        const int oy = p / W, ox = p % W;
-        float in[9][8];
+    const int64_t npix = (int64_t)B * H * W;
+    int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= npix) return;
+    int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
+    int oy = p / W, ox = p % W;
+    float in[9][8];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+    for (int t = 0; t < 9; ++t) {
+        int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+        bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float v = x[(((size_t)b * Cin + min(c, Cin - 1)) * H + cy) * W + cx];       // unconditional, clamped
-                in[t][c] = (ok && c < Cin) ? (float)(f16)v : 0.f;
-            }
-        }
+        for (int c = 0; c < 8; ++c)
+            in[t][c] = (ok && c < Cin) ? (float)(f16)x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+    }
+    for (int o8 = o8_0; o8 < o8_1; ++o8) {
         f16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const f16 *wr = s_w + (o8l * 8 + j) * 72;
+            const f16 *wr = s_w + ((o8 - o8_0) * 8 + j) * 72;
             float acc = (float)bias[o8 * 8 + j];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -541,16 +536,10 @@ __global__ __launch_bounds__(256) void k_conv_in(const float *__restrict__ x, co
 }
 int ctx_conv_in_f16(const float *x, const f16 *w, const f16 *bias, int B, int Cin, int H, int W, int Cout, f16 *y, hipStream_t s)
 {
-    if (Cin > 8 || Cout % 8 != 0) {
-        ctx_set_error("conv_in: unsupported Cin=%d Cout=%d", Cin, Cout);
-        return CTX_E_ARG;
-    }
-    const int split = cdiv(Cout * 72 * 2, 48 * 1024);           // output-channel slices whose weights fit LDS
-    const int o8per = cdiv(Cout / 8, split);
-    const size_t lds = (size_t)o8per * 8 * 72 * sizeof(f16);
-    int64_t nb = cdiv64((int64_t)B * H * W * o8per, 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_conv_in, dim3((unsigned)nb, split), dim3(256), lds, s, x, w, bias, B, Cin, H, W, Cout, y);
+    int64_t npix = (int64_t)B * H * W;
+    int o8_per = (Cout / 8 + CI_SPLIT - 1) / CI_SPLIT;
+    hipLaunchKernelGGL(k_conv_in, dim3((unsigned)cdiv64(npix, 256), CI_SPLIT), dim3(256), (size_t)o8_per * 8 * 72 * 2, s, x, w, bias, B, Cin,
+                       H, W, Cout, y);
     return CTX_OK;
 }
 
