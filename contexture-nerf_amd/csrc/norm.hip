@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void k_conv_out(const f16 *__restrict__ x, con
 int ctx_conv_out_f16(const f16 *x, const f16 *w, const f16 *bias, int B, int H, int W, int C, int Cout, float *out, hipStream_t s)
 {
     int64_t nb = cdiv64((int64_t)B * H * W, 4);
-    if (nb > 8192) nb = 8192;
+    if (nb > 512) nb = 512;                                   // every block stages the weights: keep them few and persistent
     const int nitems = 9 * (C / 8);
     const size_t lds = (size_t)Cout * 9 * C * sizeof(f16);
     if (Cout > 4 || C % 8 != 0 || nitems > 64 * 12 || lds > 64 * 1024) {

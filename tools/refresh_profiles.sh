@@ -10,7 +10,7 @@ cp gpurun_out/prof_refresh/traffic.json profiles/r01_pmc_traffic.json      # so 
 timeout -k 10 300 python3 bench.py > $OUT/bench_default.log 2>&1
 tail -1 $OUT/bench_default.log > $OUT/r01_bench_default.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/unet -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --vae 0 > $OUT/unet.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/unet -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --vae 0 --two-views 0 > $OUT/unet.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/geom -- python3 $GRAFT_REPO_ROOT/tools/bench_geometry.py > $OUT/geom.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/prof_summary.py $OUT/unet 8 70 > $OUT/r01_bench_by_kernel_and_grid.txt 2>&1
