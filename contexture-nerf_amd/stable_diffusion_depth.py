@@ -145,18 +145,26 @@ class StableDiffusion:
             return target_rgb, target_latents
         return target_rgb, intermediate_results
 
-    def img2img_step_pair(self, calls):
-        """Two img2img_step calls (two views of one mesh) with their denoise loops in flight together: two HIP streams, two
-        engines over ONE weight blob (UNet2DConditionModel.clone_shared), two schedulers.  `calls` = two dicts of
+    def img2img_step_multi(self, calls):
+        """Several img2img_step calls (views of one mesh) with their denoise loops in flight together: one HIP stream, one
+        engine (UNet2DConditionModel.clone_shared: all over ONE weight blob) and one scheduler per call.  `calls` = dicts of
         img2img_step keyword arguments.  Each result is what img2img_step(**call) returns on its own (same seeds, same
-        deterministic kernels); the pair finishes ~1.25x sooner because the deep UNet levels do not fill the chip."""
-        assert len(calls) == 2
-        if getattr(self, '_unet2', None) is None:
-            self._unet2 = self.unet.clone_shared()
-        main = torch.cuda.current_stream(self.device)
-        streams = getattr(self, '_pair_streams', None)
+        deterministic kernels); two in flight finish ~1.25x sooner, three ~1.3x, because the deep UNet levels do not fill the chip."""
+        n = len(calls)
+        if n == 1:
+            kw = dict(calls[0])
+            return [self.img2img_step(kw.pop('text_embeddings'), kw.pop('inputs'), kw.pop('original_depth_mask'), **kw)]
+        engines = getattr(self, '_engines', None)
+        if engines is None:
+            engines = self._engines = [self.unet]
+        while len(engines) < n:
+            engines.append(self.unet.clone_shared())
+        streams = getattr(self, '_multi_streams', None)
         if streams is None:
-            streams = self._pair_streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            streams = self._multi_streams = []
+        while len(streams) < n:
+            streams.append(torch.cuda.Stream(self.device))
+        main = torch.cuda.current_stream(self.device)
         jobs, metas = [], []
         with torch.no_grad():
             for k, kw in enumerate(calls):
@@ -165,23 +173,26 @@ class StableDiffusion:
                 latent_mode = kw.get('latent_mode', False)
                 latents, depth_mask, update_mask = self._prepare(kw['inputs'], kw['original_depth_mask'], kw.get('update_mask'),
                                                                  latent_mode, image_size)
-                jobs.append(StableDiffusion._Denoise(self, self.unet if k == 0 else self._unet2, self._new_scheduler(),
-                                                     kw['text_embeddings'], latents, depth_mask, kw.get('strength', 0.5),
-                                                     kw.get('num_inference_steps', 50), update_mask, kw.get('fixed_seed'),
-                                                     kw.get('guidance_scale', 100)))
+                jobs.append(StableDiffusion._Denoise(self, engines[k], self._new_scheduler(), kw['text_embeddings'], latents, depth_mask,
+                                                     kw.get('strength', 0.5), kw.get('num_inference_steps', 50), update_mask,
+                                                     kw.get('fixed_seed'), kw.get('guidance_scale', 100)))
                 metas.append(latent_mode)
-            for st in streams:
+            for st in streams[:n]:
                 st.wait_stream(main)
-            while not (jobs[0].done() and jobs[1].done()):
-                for k in range(2):
+            while not all(j.done() for j in jobs):
+                for k in range(n):
                     if not jobs[k].done():
                         with torch.cuda.stream(streams[k]):
                             jobs[k].advance()
-            for st in streams:
+            for st in streams[:n]:
                 main.wait_stream(st)
             outs = []
-            for k in range(2):
+            for k in range(n):
                 jobs[k].latents.record_stream(main)
                 rgb = self.decode_latents(jobs[k].latents)
                 outs.append((rgb, jobs[k].latents) if metas[k] else (rgb, []))
         return outs
+
+    def img2img_step_pair(self, calls):
+        assert len(calls) == 2
+        return self.img2img_step_multi(calls)

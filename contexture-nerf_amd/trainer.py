@@ -101,16 +101,19 @@ class ConTEXTure:
         cropped_rgb_output, _ = self.diffusion.img2img_step(te, inp, dm, **kw)
         return self._paint_finish(ctx, cropped_rgb_output)
 
-    def paint_viewpoints_pair(self, data_a, data_b, image_size=None, num_inference_steps=None):
-        """Two views painted with their denoise loops in flight together (StableDiffusion.img2img_step_pair): same result per
-        view as paint_viewpoint, ~1.25x sooner per pair.  Returns [(rgb_output, object_mask, last)] for the two views."""
-        preps = [self._paint_prepare(d, image_size, num_inference_steps) for d in (data_a, data_b)]
-        outs = self.diffusion.img2img_step_pair([p[0] for p in preps])
+    def paint_viewpoints_multi(self, datas, image_size=None, num_inference_steps=None):
+        """Several views painted with their denoise loops in flight together (StableDiffusion.img2img_step_multi): same result
+        per view as paint_viewpoint.  Returns [(rgb_output, object_mask, last)] per view."""
+        preps = [self._paint_prepare(d, image_size, num_inference_steps) for d in datas]
+        outs = self.diffusion.img2img_step_multi([p[0] for p in preps])
         res = []
         for (kw, ctx), (rgb, _) in zip(preps, outs):
             rgb_output, mask = self._paint_finish(ctx, rgb)
             res.append((rgb_output, mask, self._last))
         return res
+
+    def paint_viewpoints_pair(self, data_a, data_b, image_size=None, num_inference_steps=None):
+        return self.paint_viewpoints_multi([data_a, data_b], image_size, num_inference_steps)
 
     # ---- north_star "UV back-projection" (absent in the reference, SURVEY R6 / §8f n1) ----------------------------
     def project_back_scatter(self, render_cache, rgb_output, weight_mask):
@@ -139,18 +142,21 @@ class ConTEXTure:
         else:                                           # idle rank still joins the collectives
             F_ = self.mesh_model.mesh.faces.shape[0]
             D.all_reduce_max_(torch.full((F_,), float('-inf'), device=self.device), self.group)
+        # a rank that owns several views keeps `views_in_flight` of them (default 3) in the denoise loop at once
+        infl = max(1, int(getattr(self.cfg.optim, 'views_in_flight', 3)))
+        if not hasattr(self.diffusion, 'img2img_step_multi'):
+            infl = 1
         j = 0
-        pair = getattr(self.cfg.optim, 'views_in_flight', 2) >= 2 and hasattr(self.diffusion, 'img2img_step_pair')
         while j < len(mine):
-            if pair and j + 1 < len(mine):           # a rank that owns several views paints them two at a time
-                res = self.paint_viewpoints_pair(self.train_views[mine[j]], self.train_views[mine[j + 1]], image_size=image_size,
-                                                 num_inference_steps=num_inference_steps)
+            grp = mine[j:j + infl]
+            if len(grp) > 1:
+                res = self.paint_viewpoints_multi([self.train_views[k] for k in grp], image_size=image_size,
+                                                  num_inference_steps=num_inference_steps)
                 for o, (rgb, obj_mask, last) in enumerate(res):
                     contrib += self.project_back_scatter(last['render_cache'], rgb, masks[j + o:j + o + 1] & (obj_mask > 0))
-                j += 2
             else:
-                rgb, obj_mask = self.paint_viewpoint(self.train_views[mine[j]], image_size=image_size, num_inference_steps=num_inference_steps)
+                rgb, obj_mask = self.paint_viewpoint(self.train_views[grp[0]], image_size=image_size, num_inference_steps=num_inference_steps)
                 contrib += self.project_back_scatter(self._last['render_cache'], rgb, masks[j:j + 1] & (obj_mask > 0))
-                j += 1
+            j += len(grp)
         atlas, coverage = D.merge_atlas(contrib, self.group)
         return atlas, coverage
