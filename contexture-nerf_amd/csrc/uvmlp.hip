@@ -30,6 +30,7 @@ struct UvmPlan {
     int out_ch;
     int64_t out_w_off, out_b_off;
     UvmLayer layer[UVM_MAX_LAYERS];
+    int64_t wt_off[UVM_MAX_LAYERS];   // layer i >= 1: W_i[:, hidden part]^T packed as an MFMA B operand (backward chain)
 };
 
 static int uvm_build_plan(int D, int W, int input_ch, int output_ch, int skip, UvmPlan &p, int64_t &total)
@@ -47,6 +48,8 @@ static int uvm_build_plan(int D, int W, int input_ch, int output_ch, int skip, U
     }
     p.out_w_off = off; off += (int64_t)output_ch * W;
     p.out_b_off = off; off += 4;
+    p.wt_off[0] = -1;
+    for (int i = 1; i < D; ++i) { p.wt_off[i] = off; off += (int64_t)W * W; }
     total = off;
     return 0;
 }
@@ -83,6 +86,23 @@ __global__ void k_uvm_pack(const float *__restrict__ w, const float *__restrict_
     if (idx < W) db[idx] = b[idx];
 }
 
+// Backward-chain operand: dA_{i-1}[t][k] = sum_n dZ_i[t][n] * w[n][off + k]  ->  B[n][k]; packed like k_uvm_pack with the
+// contraction index n in the place of k:  dst[(kb*(W/32)+nb)*64+lane][j] = w[kb*8+4h+j][off + nb*32 + r].
+__global__ void k_uvm_pack_t(const float *__restrict__ w, int W, int kin, int off, float *__restrict__ dw)
+{
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)W * W) return;
+    int j = idx & 3;
+    int lane = (idx >> 2) & 63;
+    int64_t blk = idx >> 8;
+    int nb = blk % (W / 32);
+    int kb = blk / (W / 32);
+    int r = lane & 31, h = lane >> 5;
+    int n = kb * 8 + 4 * h + j;
+    int k = nb * 32 + r;
+    dw[idx] = w[(int64_t)n * kin + off + k];
+}
+
 __global__ void k_uvm_pack_out(const float *__restrict__ w, const float *__restrict__ b, int W, int out_ch,
                                float *__restrict__ dw, float *__restrict__ db)
 {
@@ -106,6 +126,9 @@ extern "C" int32_t ctx_uvmlp_pack(const float *const *ws, const float *const *bs
         int64_t n = (int64_t)p.layer[i].kp * W;
         hipLaunchKernelGGL(k_uvm_pack, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, ws[i], bs[i], W, kin, p.layer[i].kp,
                            input_ch, mode, dst + p.layer[i].w_off, dst + p.layer[i].b_off);
+        if (i >= 1)
+            hipLaunchKernelGGL(k_uvm_pack_t, dim3((unsigned)cdiv64((int64_t)W * W, 256)), dim3(256), 0, s, ws[i], W, kin,
+                               i == skip + 1 ? input_ch : 0, dst + p.wt_off[i]);
     }
     hipLaunchKernelGGL(k_uvm_pack_out, dim3(cdiv(output_ch * W, 256)), dim3(256), 0, s, ws[D], bs[D], W, output_ch,
                        dst + p.out_w_off, dst + p.out_b_off);
@@ -116,7 +139,7 @@ extern "C" int32_t ctx_uvmlp_pack(const float *const *ws, const float *const *bs
 template <int W>
 __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, const float *__restrict__ emb, int64_t N, int res, int L,
                                                  const float *__restrict__ packed, UvmPlan plan,
-                                                 float *__restrict__ raw, float *__restrict__ tex)
+                                                 float *__restrict__ raw, float *__restrict__ tex, float *__restrict__ saved)
 {
     constexpr int STRIDE = UVM_EPAD + W + 4;   // 308 for W=256: 4 x odd -> conflict-free ds_read_b128 rows
     static_assert((STRIDE / 4) % 2 == 1, "row stride must be 4 x odd");
@@ -154,6 +177,12 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
         }
     }
     __syncthreads();
+    if (saved) {   // training: keep the (padded) embedding for the weight gradients of layer 0 and the skip layer
+        for (int i = tid; i < UVM_TM * (UVM_EPAD / 4); i += W) {
+            int row = i / (UVM_EPAD / 4), c4 = i % (UVM_EPAD / 4);
+            if (n0 + row < N) *(float4 *)(saved + (n0 + row) * UVM_EPAD + c4 * 4) = *(const float4 *)(act + row * STRIDE + c4 * 4);
+        }
+    }
 
     // ---- hidden layers on the f32 matrix pipe --------------------------------------------------
     for (int li = 0; li < plan.n_hidden; ++li) {
@@ -200,6 +229,13 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
                 }
         }
         __syncthreads();
+        if (saved) {   // post-ReLU activations [layer][texel][W], whole rows per texel
+            float *dst = saved + N * UVM_EPAD + (int64_t)li * N * W;
+            for (int i = tid; i < UVM_TM * (W / 4); i += W) {
+                int row = i / (W / 4), c4 = i % (W / 4);
+                if (n0 + row < N) *(float4 *)(dst + (n0 + row) * W + c4 * 4) = *(const float4 *)(act + row * STRIDE + UVM_EPAD + c4 * 4);
+            }
+        }
     }
 
     // ---- output layer (W -> out_ch <= 4) on the VALU, 4 lanes per texel ------------------------
@@ -229,10 +265,17 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
     }
 }
 
-extern "C" int32_t ctx_uvmlp_fwd(const float *uv, const float *emb, int64_t N, int32_t res, const void *packed, int32_t D, int32_t W,
-                                 int32_t L, int32_t output_ch, int32_t skip, float *raw, float *tex_chw,
-                                 ctx_stream_t stream)
+extern "C" int64_t ctx_uvmlp_saved_bytes(int64_t N, int32_t D, int32_t W)
 {
+    if (N <= 0 || D < 1 || D > UVM_MAX_LAYERS || W % 64 != 0 || W > 256) return -1;
+    return N * (int64_t)(UVM_EPAD + D * W) * 4;
+}
+
+extern "C" int32_t ctx_uvmlp_fwd_save(const float *uv, const float *emb, int64_t N, int32_t res, const void *packed, int32_t D, int32_t W,
+                                      int32_t L, int32_t output_ch, int32_t skip, float *raw, float *tex_chw, void *saved_v,
+                                      ctx_stream_t stream)
+{
+    float *saved = (float *)saved_v;
     UvmPlan p; int64_t total = 0;
     CTX_REQUIRE(packed && raw && N > 0, "uvmlp_fwd: bad args");
     CTX_REQUIRE(uv || emb || (res > 1 && (int64_t)res * res == N), "uvmlp_fwd: uv == NULL needs N == res*res (N=%lld res=%d)", (long long)N, res);
@@ -245,15 +288,404 @@ extern "C" int32_t ctx_uvmlp_fwd(const float *uv, const float *emb, int64_t N, i
     const float *pk = (const float *)packed;
     if (W == 256) {
         (void)hipFuncSetAttribute((const void *)k_uvmlp_fwd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_uvmlp_fwd<256>, dim3(grid), dim3(256), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw);
+        hipLaunchKernelGGL(k_uvmlp_fwd<256>, dim3(grid), dim3(256), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw, saved);
     } else if (W == 128) {
-        hipLaunchKernelGGL(k_uvmlp_fwd<128>, dim3(grid), dim3(128), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw);
+        hipLaunchKernelGGL(k_uvmlp_fwd<128>, dim3(grid), dim3(128), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw, saved);
     } else if (W == 64) {
-        hipLaunchKernelGGL(k_uvmlp_fwd<64>, dim3(grid), dim3(64), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw);
+        hipLaunchKernelGGL(k_uvmlp_fwd<64>, dim3(grid), dim3(64), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw, saved);
     } else {
         ctx_set_error("uvmlp_fwd: W=%d unsupported (64/128/256)", W);
         return CTX_E_ARG;
     }
     CTX_CHECK_LAUNCH("uvmlp_fwd");
+    return CTX_OK;
+}
+
+extern "C" int32_t ctx_uvmlp_fwd(const float *uv, const float *emb, int64_t N, int32_t res, const void *packed, int32_t D, int32_t W,
+                                 int32_t L, int32_t output_ch, int32_t skip, float *raw, float *tex_chw,
+                                 ctx_stream_t stream)
+{
+    return ctx_uvmlp_fwd_save(uv, emb, N, res, packed, D, W, L, output_ch, skip, raw, tex_chw, nullptr, stream);
+}
+
+// =====================================================================================================================
+// Backward of the texture field (autograd of NeRF2D.forward, src/run_nerf_helpers.py:106-135, as driven by the SDS loop
+// src/training/trainer.py:644-907: atlas gradient -> tanh -> MLP -> parameter gradients; uv is not trainable).
+//
+// Two phases, both on the exact-f32 matrix pipe:
+//   k_uvmlp_dgrad : per 64-texel tile, the chain dA_7 = draw . Wout; dZ_i = dA_i * (A_i > 0); dA_{i-1} = dZ_i . W_i[:, hidden]
+//                   with dA resident in LDS; every dZ_i goes to HBM [layer][texel][W] (whole rows), and the output layer's
+//                   weight / bias gradients are accumulated on the VALU on the way.
+//   k_uvmlp_wgrad : dW_i = dZ_i^T . In_i as a split-K GEMM over the texels: a workgroup owns the whole W x cols gradient
+//                   in registers (256 accumulator VGPRs per lane for 256 x 256) and walks its texel range two texels per
+//                   MFMA k-step; both operands are texel-major, so a lane's operand is ONE dword of a 128-byte row segment
+//                   straight from global memory (no LDS, no transposes).  db_i = column sums of dZ_i ride along.
+//                   Partial gradients land in per-workgroup slabs and are summed in a fixed order (deterministic).
+// =====================================================================================================================
+#define UVM_WG_GROUPS 256       // workgroups (= texel ranges) of the weight-gradient GEMMs
+#define UVM_DGRAD_GRID 512      // persistent dgrad workgroups (2 per CU)
+
+template <int W>
+__global__ __launch_bounds__(W) void k_uvmlp_dgrad(const float *__restrict__ grad_raw, const float *__restrict__ grad_tex,
+                                                   const float *__restrict__ raw, int64_t N, const float *__restrict__ packed,
+                                                   UvmPlan plan, const float *__restrict__ saved, float *__restrict__ dz,
+                                                   float *__restrict__ part_w /*[grid][4][W]*/, float *__restrict__ part_b /*[grid][4]*/)
+{
+    constexpr int STRIDE = W + 4;               // 4 x odd
+    constexpr int C4N = W / 4;                  // float4 per row; W threads -> 4 rows per pass, 16 passes per tile
+    extern __shared__ __attribute__((aligned(16))) float g[];   // [64][STRIDE] dA / dZ, then dr[64][4]
+    float *dr = g + UVM_TM * STRIDE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int c4 = tid % C4N, rg = tid / C4N;
+    const int D = plan.n_hidden;
+    const float *acts = saved + N * UVM_EPAD;
+
+    float wo[4][4], gwo[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wo[c][j] = c < plan.out_ch ? packed[plan.out_w_off + c * W + c4 * 4 + j] : 0.f;
+            gwo[c][j] = 0.f;
+        }
+    float gbo = 0.f;                            // this thread's channel is tid & 3
+
+    const int64_t ntiles = (N + UVM_TM - 1) / UVM_TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n0 = tile * UVM_TM;
+        // ---- d loss / d raw for the tile's 64 texels --------------------------------------------
+        for (int i = tid; i < UVM_TM * 4; i += W) {
+            int t = i >> 2, c = i & 3;
+            int64_t n = n0 + t;
+            float v = 0.f;
+            if (n < N && c < plan.out_ch) {
+                if (grad_raw) v = grad_raw[n * plan.out_ch + c];
+                if (grad_tex) {
+                    float y = tanhf(raw[n * plan.out_ch + c]);
+                    v += grad_tex[(int64_t)c * N + n] * 0.5f * (1.0f - y * y);
+                }
+            }
+            dr[i] = v;
+            gbo += v;
+        }
+        __syncthreads();
+        // ---- output layer: dA = draw . Wout, dWout += draw^T . A, dZ = dA * (A > 0) -----------
+        {
+            const float *a_top = acts + (int64_t)(D - 1) * N * W;
+            float *dz_top = dz + (int64_t)(D - 1) * N * W;
+#pragma unroll 4
+            for (int p = 0; p < UVM_TM / 4; ++p) {
+                int t = p * 4 + rg;
+                int64_t n = n0 + t;
+                int64_t nc = n < N ? n : N - 1;
+                float4 a = *(const float4 *)(a_top + nc * W + c4 * 4);
+                float4 d = *(const float4 *)(dr + t * 4);
+                const float av[4] = {a.x, a.y, a.z, a.w}, dv[4] = {d.x, d.y, d.z, d.w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float da = dv[0] * wo[0][j];
+                    da = fmaf(dv[1], wo[1][j], da);
+                    da = fmaf(dv[2], wo[2][j], da);
+                    da = fmaf(dv[3], wo[3][j], da);
+                    o[j] = av[j] > 0.f ? da : 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gwo[c][j] = fmaf(dv[c], av[j], gwo[c][j]);
+                }
+                float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+                *(float4 *)(g + t * STRIDE + c4 * 4) = ov;
+                if (n < N) *(float4 *)(dz_top + n * W + c4 * 4) = ov;
+            }
+        }
+        __syncthreads();
+        // ---- hidden layers, last to second ------------------------------------------------------
+        for (int li = D - 1; li >= 1; --li) {
+            const float *a_prev = acts + (int64_t)(li - 1) * N * W;
+            float *dz_prev = dz + (int64_t)(li - 1) * N * W;
+            float4 pre[UVM_TM / 4];              // A_{li-1} of the tile: the ReLU mask, fetched under the MFMAs
+#pragma unroll
+            for (int p = 0; p < UVM_TM / 4; ++p) {
+                int64_t n = n0 + p * 4 + rg;
+                int64_t nc = n < N ? n : N - 1;
+                pre[p] = *(const float4 *)(a_prev + nc * W + c4 * 4);
+            }
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+            const float4 *wp = (const float4 *)(packed + plan.wt_off[li]) + ((size_t)(wave * 2) * 64 + lane);
+            const float *arow0 = g + r * STRIDE + 4 * h;
+            const float *arow1 = arow0 + 32 * STRIDE;
+            for (int kb = 0; kb < W / 8; ++kb) {
+                float4 b0 = wp[(size_t)kb * (W / 32) * 64];
+                float4 b1 = wp[(size_t)kb * (W / 32) * 64 + 64];
+                float4 a0 = *(const float4 *)(arow0 + kb * 8);
+                float4 a1 = *(const float4 *)(arow1 + kb * 8);
+                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+                const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+                }
+            }
+            __syncthreads();                     // all fragment reads of dZ_li done
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                int col = wave * 64 + nb * 32 + r;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        int row = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                        g[row * STRIDE + col] = acc[mb][nb][q];
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < UVM_TM / 4; ++p) {
+                int t = p * 4 + rg;
+                int64_t n = n0 + t;
+                float4 v = *(const float4 *)(g + t * STRIDE + c4 * 4);
+                v.x = pre[p].x > 0.f ? v.x : 0.f;
+                v.y = pre[p].y > 0.f ? v.y : 0.f;
+                v.z = pre[p].z > 0.f ? v.z : 0.f;
+                v.w = pre[p].w > 0.f ? v.w : 0.f;
+                *(float4 *)(g + t * STRIDE + c4 * 4) = v;
+                if (n < N) *(float4 *)(dz_prev + n * W + c4 * 4) = v;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- output-layer gradients of this workgroup: fold the 4 row groups, one partial row per channel ----
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[(rg * 4 + c) * W + c4 * 4 + j] = gwo[c][j];
+    __syncthreads();
+    for (int c = 0; c < 4; ++c) {
+        float s = g[(0 * 4 + c) * W + tid];
+        s += g[(1 * 4 + c) * W + tid];
+        s += g[(2 * 4 + c) * W + tid];
+        s += g[(3 * 4 + c) * W + tid];
+        part_w[((int64_t)blockIdx.x * 4 + c) * W + tid] = s;
+    }
+    dr[tid] = gbo;
+    __syncthreads();
+    if (tid < 4) {
+        float s = 0.f;
+        for (int i = tid; i < W; i += 4) s += dr[i];
+        part_b[(int64_t)blockIdx.x * 4 + tid] = s;
+    }
+}
+
+// dW[rows x cols] = dZ^T . In over the texel range of this workgroup.  Waves WR x WC, wave tile (32 NI) x (32 NJ).
+template <int WR, int WC, int NI, int NJ>
+__global__ __launch_bounds__(64 * WR * WC) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_uvmlp_wgrad(const float *__restrict__ dz, int ldz, const float *__restrict__ in, int ldin, int in_cols, int64_t N,
+                   int64_t chunk, float *__restrict__ slab, float *__restrict__ bslab)
+{
+    constexpr int ROWS = WR * NI * 32, COLS = WC * NJ * 32;
+    constexpr int U = 4;                         // k-steps (2 texels each) per buffer
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave / WC, wc = wave % WC;
+    const int row0 = wr * NI * 32, col0 = wc * NJ * 32;
+    const int64_t t_begin = (int64_t)blockIdx.x * chunk;
+    const int64_t t_end = t_begin + chunk < N ? t_begin + chunk : N;
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    float bs[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bs[i] = 0.f;
+    int bcol[NJ]; bool bok[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int cc = col0 + j * 32 + r;
+        bok[j] = cc < in_cols;
+        bcol[j] = bok[j] ? cc : in_cols - 1;
+    }
+
+    float a0[U][NI], b0[U][NJ], a1[U][NI], b1[U][NJ];
+    auto fetch = [&](int64_t t, float (&a)[U][NI], float (&b)[U][NJ]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t tt = t + 2 * u + h;
+            bool ok = tt < t_end;
+            int64_t tc = tt < N ? tt : N - 1;
+            const float *zp = dz + tc * ldz + row0 + r;
+            const float *ip = in + tc * ldin;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { float v = zp[i * 32]; a[u][i] = ok ? v : 0.f; }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { float v = ip[bcol[j]]; b[u][j] = bok[j] ? v : 0.f; }
+        }
+    };
+    auto mma = [&](const float (&a)[U][NI], const float (&b)[U][NJ]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+                if (wc == 0) bs[i] += a[u][i];
+            }
+        }
+    };
+    fetch(t_begin, a0, b0);
+    for (int64_t t = t_begin; t < t_end; t += 4 * U) {
+        fetch(t + 2 * U, a1, b1);                // past-the-end fetches are clamped and zeroed
+        mma(a0, b0);
+        fetch(t + 4 * U, a0, b0);
+        mma(a1, b1);
+    }
+    float *sl = slab + (int64_t)blockIdx.x * ROWS * COLS;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int n = row0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                sl[n * COLS + col0 + j * 32 + r] = acc[i][j][q];
+            }
+    if (wc == 0 && bslab) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float v = bs[i] + __shfl_xor(bs[i], 32, 64);
+            if (h == 0) bslab[(int64_t)blockIdx.x * ROWS + row0 + i * 32 + r] = v;
+        }
+    }
+}
+
+// out[n][col_off + k] = sum_g slab[g][n][k]  (fixed order), k < out_cols.
+__global__ void k_uvm_reduce(const float *__restrict__ slab, int G, int64_t stride, int rows, int cols_pad, int out_cols,
+                             float *__restrict__ out, int ld_out, int col_off)
+{
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * cols_pad) return;
+    int n = idx / cols_pad, k = idx % cols_pad;
+    if (k >= out_cols) return;
+    const float *p = slab + idx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int gi = 0;
+    for (; gi + 4 <= G; gi += 4) {
+        s0 += p[(gi + 0) * stride]; s1 += p[(gi + 1) * stride];
+        s2 += p[(gi + 2) * stride]; s3 += p[(gi + 3) * stride];
+    }
+    for (; gi < G; ++gi) s0 += p[gi * stride];
+    out[(int64_t)n * ld_out + col_off + k] = (s0 + s1) + (s2 + s3);
+}
+
+static inline int64_t uvm_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+extern "C" int64_t ctx_uvmlp_bwd_ws_bytes(int64_t N, int32_t D, int32_t W)
+{
+    if (N <= 0 || D < 1 || D > UVM_MAX_LAYERS || W % 64 != 0 || W > 256) return -1;
+    int64_t b = uvm_align((int64_t)D * N * W * 4);                       // dZ
+    b += uvm_align((int64_t)UVM_WG_GROUPS * W * (W > 64 ? W : 64) * 4);  // weight-gradient slabs
+    b += uvm_align((int64_t)UVM_WG_GROUPS * W * 4);                      // bias slabs
+    b += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * W * 4);                 // output-layer weight partials
+    b += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * 4);                     // output-layer bias partials
+    return b;
+}
+
+template <int WR, int WC, int NI, int NJ>
+static void uvm_launch_wgrad(int G, const float *dz, int ldz, const float *in, int ldin, int in_cols, int64_t N, int64_t chunk,
+                             float *slab, float *bslab, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_uvmlp_wgrad<WR, WC, NI, NJ>), dim3(G), dim3(64 * WR * WC), 0, s, dz, ldz, in, ldin, in_cols, N, chunk,
+                       slab, bslab);
+}
+
+extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, const float *raw, int64_t N, const void *packed,
+                                 int32_t D, int32_t W, int32_t L, int32_t output_ch, int32_t skip, const void *saved_v, void *ws,
+                                 float *const *gws, float *const *gbs, ctx_stream_t stream)
+{
+    UvmPlan p; int64_t total = 0;
+    CTX_REQUIRE(packed && saved_v && ws && gws && gbs && N > 0, "uvmlp_bwd: bad args");
+    CTX_REQUIRE(grad_raw || grad_tex, "uvmlp_bwd: need grad_raw and / or grad_tex");
+    CTX_REQUIRE(!grad_tex || raw, "uvmlp_bwd: grad_tex needs raw (the tanh argument)");
+    int input_ch = 2 * (1 + 2 * L);
+    CTX_REQUIRE(uvm_build_plan(D, W, input_ch, output_ch, skip, p, total) == 0,
+                "uvmlp_bwd: unsupported D=%d W=%d L=%d output_ch=%d", D, W, L, output_ch);
+    CTX_REQUIRE(skip >= 0 && skip + 1 < D, "uvmlp_bwd: skip=%d outside [0, D-2]", skip);
+    for (int i = 0; i <= D; ++i) CTX_REQUIRE(gws[i] && gbs[i], "uvmlp_bwd: null gradient pointer for layer %d", i);
+    hipStream_t s = (hipStream_t)stream;
+    const float *pk = (const float *)packed;
+    const float *saved = (const float *)saved_v;
+    char *wp = (char *)ws;
+    float *dz = (float *)wp;          wp += uvm_align((int64_t)D * N * W * 4);
+    float *slab = (float *)wp;        wp += uvm_align((int64_t)UVM_WG_GROUPS * W * (W > 64 ? W : 64) * 4);
+    float *bslab = (float *)wp;       wp += uvm_align((int64_t)UVM_WG_GROUPS * W * 4);
+    float *part_w = (float *)wp;      wp += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * W * 4);
+    float *part_b = (float *)wp;
+
+    // ---- phase 1: the dZ chain ----
+    int64_t ntiles = cdiv64(N, UVM_TM);
+    int dg = (int)(ntiles < UVM_DGRAD_GRID ? ntiles : UVM_DGRAD_GRID);
+    size_t lds = (size_t)(UVM_TM * (W + 4) + UVM_TM * 4) * 4;
+    if (W == 256) {
+        (void)hipFuncSetAttribute((const void *)k_uvmlp_dgrad<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_uvmlp_dgrad<256>, dim3(dg), dim3(256), lds, s, grad_raw, grad_tex, raw, N, pk, p, saved, dz, part_w, part_b);
+    } else if (W == 128) {
+        hipLaunchKernelGGL(k_uvmlp_dgrad<128>, dim3(dg), dim3(128), lds, s, grad_raw, grad_tex, raw, N, pk, p, saved, dz, part_w, part_b);
+    } else {
+        hipLaunchKernelGGL(k_uvmlp_dgrad<64>, dim3(dg), dim3(64), lds, s, grad_raw, grad_tex, raw, N, pk, p, saved, dz, part_w, part_b);
+    }
+    CTX_CHECK_LAUNCH("uvmlp_dgrad");
+    hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(output_ch * W, 256)), dim3(256), 0, s, part_w, dg, (int64_t)4 * W, output_ch, W, W,
+                       gws[D], W, 0);
+    hipLaunchKernelGGL(k_uvm_reduce, dim3(1), dim3(256), 0, s, part_b, dg, (int64_t)4, 1, 4, output_ch, gbs[D], 4, 0);
+    CTX_CHECK_LAUNCH("uvmlp_reduce_out");
+
+    // ---- phase 2: weight / bias gradients ----
+    int64_t chunk = cdiv64(N, UVM_WG_GROUPS);
+    chunk = (chunk + 15) / 16 * 16;              // whole double-buffer rounds (2 x 4 k-steps x 2 texels)
+    int G = (int)cdiv64(N, chunk);
+    const float *emb = saved;
+    const float *acts = saved + N * UVM_EPAD;
+    for (int li = D - 1; li >= 0; --li) {
+        const float *dzl = dz + (int64_t)li * N * W;
+        const int kin = li == 0 ? input_ch : (li == skip + 1 ? input_ch + W : W);
+        const bool has_emb = li == 0 || li == skip + 1;
+        const bool has_hid = li != 0;
+        if (has_hid) {
+            const float *in = acts + (int64_t)(li - 1) * N * W;
+            if (W == 256) uvm_launch_wgrad<2, 2, 4, 4>(G, dzl, W, in, W, W, N, chunk, slab, bslab, s);
+            else if (W == 128) uvm_launch_wgrad<2, 2, 2, 2>(G, dzl, W, in, W, W, N, chunk, slab, bslab, s);
+            else uvm_launch_wgrad<2, 2, 1, 1>(G, dzl, W, in, W, W, N, chunk, slab, bslab, s);
+            CTX_CHECK_LAUNCH("uvmlp_wgrad");
+            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * W, 256)), dim3(256), 0, s, slab, G, (int64_t)W * W, W, W, W, gws[li], kin,
+                               has_emb ? input_ch : 0);
+            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W, 256)), dim3(256), 0, s, bslab, G, (int64_t)W, 1, W, W, gbs[li], W, 0);
+        }
+        if (has_emb) {
+            float *bsl = has_hid ? nullptr : bslab;
+            if (W == 256) uvm_launch_wgrad<4, 1, 2, 2>(G, dzl, W, emb, UVM_EPAD, UVM_EPAD, N, chunk, slab, bsl, s);
+            else if (W == 128) uvm_launch_wgrad<2, 1, 2, 2>(G, dzl, W, emb, UVM_EPAD, UVM_EPAD, N, chunk, slab, bsl, s);
+            else uvm_launch_wgrad<1, 1, 2, 2>(G, dzl, W, emb, UVM_EPAD, UVM_EPAD, N, chunk, slab, bsl, s);
+            CTX_CHECK_LAUNCH("uvmlp_wgrad_emb");
+            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * 64, 256)), dim3(256), 0, s, slab, G, (int64_t)W * 64, W, 64, input_ch, gws[li], kin, 0);
+            if (!has_hid)
+                hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W, 256)), dim3(256), 0, s, bslab, G, (int64_t)W, 1, W, W, gbs[li], W, 0);
+        }
+        CTX_CHECK_LAUNCH("uvmlp_wgrad_reduce");
+    }
     return CTX_OK;
 }

@@ -5,7 +5,9 @@ NeRF2D keeps the reference's parameter names (`pts_linears.{i}.{weight,bias}`, `
 initialisation order so a reference state_dict loads unchanged and a seeded construction gives the same
 weights.  forward(embedded) runs the fused fp32-MFMA kernel; `texture_map(res)` is the fully fused
 uv -> embed -> MLP -> (tanh+1)/2 path used by TexturedMeshModel.get_texture_map.
-Forward only on the HIP path this round (SDS backward is SURVEY §8f n3).
+When gradients are enabled and a parameter requires them, the forward keeps the activations
+(`ctx_uvmlp_fwd_save`) and `backward` runs `ctx_uvmlp_bwd` (the texture side of the SDS loop,
+src/training/trainer.py:644-907): parameter gradients only — uv / the embedding are not trainable inputs.
 """
 import ctypes as C
 import numpy as np
@@ -37,6 +39,47 @@ def get_embedder(multires, i=0):
         return nn.Identity(), 2
     eo = Embedder(2, multires)
     return (lambda x, eo=eo: eo.embed(x)), eo.out_dim
+
+
+class _UvMlpFn(torch.autograd.Function):
+    """(raw [N,C], tex [C,N] or None) = field(uv | emb | grid(res)); gradients flow to the nn.Linear parameters."""
+
+    @staticmethod
+    def forward(ctx, net, uv, emb, N, res, want_tex, *params):
+        lib = L.load()
+        blob = net.packed()
+        dev = blob.device
+        Lf = (net.input_ch // 2 - 1) // 2
+        raw = torch.empty(N, net.output_ch, device=dev)
+        tex = torch.empty(net.output_ch, N, device=dev) if want_tex else None
+        saved = torch.empty(lib.ctx_uvmlp_saved_bytes(N, net.D, net.W), dtype=torch.uint8, device=dev)
+        L.check(lib.ctx_uvmlp_fwd_save(L.ptr(uv), L.ptr(emb), N, res, L.ptr(blob), net.D, net.W, Lf, net.output_ch,
+                                       net.skips[0], L.ptr(raw), L.ptr(tex), L.ptr(saved), L.stream()))
+        ctx.net, ctx.N, ctx.saved_acts, ctx.raw, ctx.blob = net, N, saved, raw, blob
+        ctx.set_materialize_grads(False)
+        return (raw, tex) if want_tex else raw
+
+    @staticmethod
+    def backward(ctx, g_raw, g_tex=None):
+        lib = L.load()
+        net, N = ctx.net, ctx.N
+        dev = ctx.raw.device
+        layers = list(net.pts_linears) + [net.output_linear]
+        gws = [torch.empty_like(l.weight) for l in layers]
+        gbs = [torch.empty_like(l.bias) for l in layers]
+        ws = torch.empty(lib.ctx_uvmlp_bwd_ws_bytes(N, net.D, net.W), dtype=torch.uint8, device=dev)
+        gwp = (C.c_void_p * len(gws))(*[L.ptr(g).value for g in gws])
+        gbp = (C.c_void_p * len(gbs))(*[L.ptr(g).value for g in gbs])
+        g_raw = None if g_raw is None else L.f32c(g_raw)
+        g_tex = None if g_tex is None else L.f32c(g_tex)
+        Lf = (net.input_ch // 2 - 1) // 2
+        L.check(lib.ctx_uvmlp_bwd(L.ptr(g_raw), L.ptr(g_tex), L.ptr(ctx.raw), N, L.ptr(ctx.blob), net.D, net.W, Lf,
+                                  net.output_ch, net.skips[0], L.ptr(ctx.saved_acts), L.ptr(ws), gwp, gbp, L.stream()))
+        ctx.saved_acts = None
+        grads = []
+        for w, b in zip(gws, gbs):
+            grads += [w, b]
+        return (None, None, None, None, None, None, *grads)
 
 
 class NeRF2D(nn.Module):
@@ -79,7 +122,16 @@ class NeRF2D(nn.Module):
             self._packed, self._packed_version = blob, v
         return self._packed
 
+    def _params(self):
+        out = []
+        for l in list(self.pts_linears) + [self.output_linear]:
+            out += [l.weight, l.bias]
+        return out
+
     def _run(self, uv, emb, N, res, want_tex):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            r = _UvMlpFn.apply(self, uv, emb, N, res, want_tex, *self._params())
+            return r if want_tex else (r, None)
         lib = L.load()
         blob = self.packed()
         dev = blob.device

@@ -59,6 +59,7 @@ class ConTEXTure:
         return self.view_weights
 
     # ---- trainer.py:971-1117 ---------------------------------------------------------------------------------
+    @torch.no_grad()   # the paint pass is inference; the texture field keeps activations only when gradients are on
     def _paint_prepare(self, data, image_size=None, num_inference_steps=None):
         """Everything of paint_viewpoint up to the diffusion call: render, crop box; returns (img2img kwargs, context)."""
         theta, phi, radius = data['theta'], data['phi'], data['radius']
@@ -87,6 +88,7 @@ class ConTEXTure:
                    box=(min_h, min_w, max_h, max_w), crop_hw=(cropped_rgb_render.shape[2], cropped_rgb_render.shape[3]))
         return kw, ctx
 
+    @torch.no_grad()
     def _paint_finish(self, ctx, cropped_rgb_output):
         cropped_rgb_output = F.interpolate(cropped_rgb_output, ctx['crop_hw'], mode='bilinear', align_corners=False)
         min_h, min_w, max_h, max_w = ctx['box']

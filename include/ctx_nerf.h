@@ -120,6 +120,23 @@ int32_t ctx_uvmlp_fwd(const float *uv /*nullable*/, const float *emb /*nullable*
                       int32_t D, int32_t W, int32_t L, int32_t output_ch, int32_t skip,
                       float *raw, float *tex_chw /*nullable*/, ctx_stream_t stream);
 
+/* Training forward: as ctx_uvmlp_fwd, and keeps what the backward needs in `saved`
+   (ctx_uvmlp_saved_bytes(N,D,W) bytes: the padded embedding [N,48] and the post-ReLU activations [D,N,W], fp32). */
+int64_t ctx_uvmlp_saved_bytes(int64_t N, int32_t D, int32_t W);
+int32_t ctx_uvmlp_fwd_save(const float *uv /*nullable*/, const float *emb /*nullable*/, int64_t N, int32_t res, const void *packed,
+                           int32_t D, int32_t W, int32_t L, int32_t output_ch, int32_t skip,
+                           float *raw, float *tex_chw /*nullable*/, void *saved /*nullable: plain forward*/, ctx_stream_t stream);
+/* Backward of NeRF2D.forward (autograd of src/run_nerf_helpers.py:106-135; the SDS loop src/training/trainer.py:644-907
+   drives it with the atlas gradient).  Upstream gradient: grad_raw [N,output_ch] (d loss / d mlp_output) and / or
+   grad_tex [output_ch,N] (d loss / d texture atlas of textured_mesh.py:298-301; the (tanh+1)/2 is differentiated
+   here from `raw`).  Writes (not accumulates) d loss / d weight into gws[i] ([out_i,in_i], nn.Linear layout) and
+   d loss / d bias into gbs[i], i = 0..D-1 hidden, D = output_linear (host arrays of device pointers).
+   ws: ctx_uvmlp_bwd_ws_bytes(N,D,W) bytes of scratch.  Deterministic (fixed-order partial sums). */
+int64_t ctx_uvmlp_bwd_ws_bytes(int64_t N, int32_t D, int32_t W);
+int32_t ctx_uvmlp_bwd(const float *grad_raw /*nullable*/, const float *grad_tex /*nullable*/, const float *raw /*nullable w/o grad_tex*/,
+                      int64_t N, const void *packed, int32_t D, int32_t W, int32_t L, int32_t output_ch, int32_t skip,
+                      const void *saved, void *ws, float *const *gws, float *const *gbs, ctx_stream_t stream);
+
 /* ---- ray path (north_star; dead/absent in the reference) ------------------------ */
 /* get_rays (run_nerf_helpers.py:139-148): K row-major [3,3] host floats passed by value fields. */
 int32_t ctx_get_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy,

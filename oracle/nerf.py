@@ -2,6 +2,8 @@
 
   embed          : run_nerf_helpers.py:15-65   (Embedder, get_embedder(multires); freq = 2**linspace(0,L-1,L), no pi)
   nerf2d_forward : run_nerf_helpers.py:68-135  (NeRF2D; skip-cat AFTER layer `skips`, input first)
+  nerf2d_backward: reverse-mode derivative of the same forward (what autograd computes for run_nerf_helpers.py:106-135,
+                   with the (tanh+1)/2 head of textured_mesh.py:298-301 when grad_tex is given)
   get_rays       : run_nerf_helpers.py:139-148
   ndc_rays       : run_nerf_helpers.py:162-180
   sample_pdf     : run_nerf_helpers.py:184-225
@@ -29,6 +31,45 @@ def nerf2d_forward(e, weights, biases, out_w, out_b, skips=(4,), dtype=np.float3
         if i in skips:
             h = np.concatenate([e, h], -1)
     return h @ np.asarray(out_w, dtype).T + np.asarray(out_b, dtype)
+
+
+def nerf2d_backward(e, weights, biases, out_w, out_b, grad_raw=None, grad_tex=None, skips=(4,), dtype=np.float64, masks=None,
+                    return_pre=False):
+    """Parameter gradients of NeRF2D.  grad_raw: d loss / d raw [N,C]; grad_tex: d loss / d ((tanh(raw)+1)/2) [N,C].
+    Returns (gws, gbs) with index D = output_linear, nn.Linear layouts.
+    masks (optional, list of bool [N,W]): the ReLU derivative pattern to use instead of (pre-activation > 0) — a comparison
+    against an fp32 implementation must share the pattern, since a unit whose pre-activation is ~1e-7 may round to either
+    side and one flipped unit moves a gradient entry by a whole term.  return_pre: also return the pre-activations."""
+    e = np.asarray(e, dtype)
+    ins, acts, pre = [], [], []
+    h = e
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        ins.append(h)
+        z = h @ np.asarray(w, dtype).T + np.asarray(b, dtype)
+        pre.append(z)
+        h = np.maximum(z, 0)
+        acts.append(h)
+        if i in skips:
+            h = np.concatenate([e, h], -1)
+    raw = h @ np.asarray(out_w, dtype).T + np.asarray(out_b, dtype)
+    g = np.zeros_like(raw)
+    if grad_raw is not None:
+        g = g + np.asarray(grad_raw, dtype)
+    if grad_tex is not None:
+        g = g + np.asarray(grad_tex, dtype) * 0.5 * (1 - np.tanh(raw) ** 2)
+    D = len(weights)
+    gws, gbs = [None] * (D + 1), [None] * (D + 1)
+    gws[D] = g.T @ h
+    gbs[D] = g.sum(0)
+    dh = g @ np.asarray(out_w, dtype)                   # wrt the input of output_linear (no skip-cat after the last layer)
+    for i in range(D - 1, -1, -1):
+        if i in skips:
+            dh = dh[:, e.shape[1]:]                     # the cat put the (non-trainable) embedding first
+        dz = dh * ((acts[i] > 0) if masks is None else masks[i])
+        gws[i] = dz.T @ ins[i]
+        gbs[i] = dz.sum(0)
+        dh = dz @ np.asarray(weights[i], dtype)
+    return (gws, gbs, pre) if return_pre else (gws, gbs)
 
 
 def texture_from_mlp(mlp_out, res):

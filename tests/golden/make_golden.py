@@ -86,12 +86,23 @@ def main():
     out['nerf2d_seed1234_gw0'] = net.pts_linears[0].weight.grad.numpy()
     out['nerf2d_seed1234_gb_out'] = net.output_linear.bias.grad.numpy()
     out['nerf2d_seed1234_gw5_sum'] = np.array(net.pts_linears[5].weight.grad.double().sum().item())
+    # more of the same backward pass (pins the oracle's / the HIP path's NeRF2D backward)
+    out['nerf2d_seed1234_gw5'] = net.pts_linears[5].weight.grad.numpy()
+    out['nerf2d_seed1234_gw7'] = net.pts_linears[7].weight.grad.numpy()
+    out['nerf2d_seed1234_gw_out'] = net.output_linear.weight.grad.numpy()
+    for i in range(8):
+        out[f'nerf2d_seed1234_gb{i}'] = net.pts_linears[i].bias.grad.numpy()
     # small net with stored weights (independent of torch RNG stream)
     torch.manual_seed(7)
     small = rnh.NeRF2D(D=8, W=64, input_ch=42, output_ch=3, skips=[4])
     for k, v in small.state_dict().items():
         out['small_' + k] = v.numpy()
-    out['small_y'] = small(e).detach().numpy()
+    ys = small(e)
+    out['small_y'] = ys.detach().numpy()
+    # backward through the texture head of textured_mesh.py:298-301: loss = sum(((tanh(y)+1)/2) * c)
+    (((torch.tanh(ys) + 1) / 2) * torch.linspace(-1, 1, ys.numel()).reshape(ys.shape)).sum().backward()
+    for k, v in small.named_parameters():
+        out['smallgrad_' + k] = v.grad.numpy()
 
     # rays
     H, W = 6, 8

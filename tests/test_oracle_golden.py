@@ -22,6 +22,20 @@ def test_nerf2d_small_stored_weights(golden):
     np.testing.assert_allclose(y, golden['small_y'], rtol=1e-4, atol=1e-5)
 
 
+def test_nerf2d_backward_small_stored_weights(golden):
+    """oracle backward vs the reference's autograd (tests/golden/make_golden.py: loss = sum(((tanh(y)+1)/2) * linspace))."""
+    ws = [golden[f'small_pts_linears.{i}.weight'] for i in range(8)]
+    bs = [golden[f'small_pts_linears.{i}.bias'] for i in range(8)]
+    c = np.linspace(-1, 1, 96 * 3, dtype=np.float32).reshape(96, 3)
+    gws, gbs = onerf.nerf2d_backward(golden['embed_y'], ws, bs, golden['small_output_linear.weight'],
+                                     golden['small_output_linear.bias'], grad_tex=c)
+    for i in range(8):
+        np.testing.assert_allclose(gws[i], golden[f'smallgrad_pts_linears.{i}.weight'], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(gbs[i], golden[f'smallgrad_pts_linears.{i}.bias'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gws[8], golden['smallgrad_output_linear.weight'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gbs[8], golden['smallgrad_output_linear.bias'], rtol=2e-4, atol=2e-5)
+
+
 def test_rays_and_sampling(golden):
     ro, rd = onerf.get_rays(6, 8, golden['rays_K'], golden['rays_c2w'])
     np.testing.assert_allclose(rd, golden['rays_d'], rtol=1e-6, atol=1e-6)
