@@ -12,10 +12,21 @@
 // lane's four k-steps of an 8-wide k-block are one 16-byte global load (L2-resident: 1.9 MB).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define UVM_MAX_LAYERS 16
 #define UVM_EPAD 48       // padded embedding width (42 -> 48)
 #define UVM_TM 64         // texels per workgroup
+
+// Weight fragments of the NEXT k-block are fetched while the current one feeds the matrix pipe.  hipcc re-materialises a plain
+// C++ prefetch (it proves the carried value equals a load of this iteration's address and re-loads it at the loop top), so the
+// prefetched block index is laundered through an empty asm: the value then has to be carried in registers.  The K loops
+// are unrolled by two over two register sets so that carrying costs no copies.
+__device__ __forceinline__ int uvm_opaque(int k)
+{
+    asm volatile("" : "+s"(k));
+    return k;
+}
 
 struct UvmLayer {
     int col0;       // first LDS column read
@@ -198,9 +209,7 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
         const int nkb = ly.kp / 8;
         const float *arow0 = act + r * STRIDE + ly.col0 + 4 * h;
         const float *arow1 = arow0 + 32 * STRIDE;
-        for (int kb = 0; kb < nkb; ++kb) {
-            float4 b0 = wp[(size_t)kb * (W / 32) * 64];
-            float4 b1 = wp[(size_t)kb * (W / 32) * 64 + 64];
+        auto kstep = [&](int kb, const float4 &b0, const float4 &b1) {
             float4 a0 = *(const float4 *)(arow0 + kb * 8);
             float4 a1 = *(const float4 *)(arow1 + kb * 8);
             const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
@@ -212,6 +221,18 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
             }
+        };
+        constexpr size_t KBS = (size_t)(W / 32) * 64;   // float4 per k-block
+        float4 wa0 = wp[0], wa1 = wp[64], wb0, wb1;
+        for (int kb = 0; kb < nkb; kb += 2) {            // every padded K is a multiple of 16
+            const float4 *pb = wp + (size_t)uvm_opaque(kb + 1) * KBS;
+            wb0 = pb[0]; wb1 = pb[64];
+            __builtin_amdgcn_sched_barrier(0);           // keep the prefetch above the MFMAs it hides under
+            kstep(kb, wa0, wa1);
+            const float4 *pa = wp + (size_t)uvm_opaque(kb + 2 < nkb ? kb + 2 : kb) * KBS;
+            wa0 = pa[0]; wa1 = pa[64];
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(kb + 1, wb0, wb1);
         }
         __syncthreads();   // everyone has finished reading this layer's input
         const float *bias = packed + ly.b_off;
@@ -323,10 +344,11 @@ extern "C" int32_t ctx_uvmlp_fwd(const float *uv, const float *emb, int64_t N, i
 //                   Partial gradients land in per-workgroup slabs and are summed in a fixed order (deterministic).
 // =====================================================================================================================
 #define UVM_WG_GROUPS 256       // workgroups (= texel ranges) of the weight-gradient GEMMs
+#define UVM_WG_GROUPS_EMB 768   // the 48-column embedding gradients run 3 workgroups per CU
 #define UVM_DGRAD_GRID 512      // persistent dgrad workgroups (2 per CU)
 
 template <int W>
-__global__ __launch_bounds__(W) void k_uvmlp_dgrad(const float *__restrict__ grad_raw, const float *__restrict__ grad_tex,
+__global__ __launch_bounds__(W, 2) void k_uvmlp_dgrad(const float *__restrict__ grad_raw, const float *__restrict__ grad_tex,
                                                    const float *__restrict__ raw, int64_t N, const float *__restrict__ packed,
                                                    UvmPlan plan, const float *__restrict__ saved, float *__restrict__ dz,
                                                    float *__restrict__ part_w /*[grid][4][W]*/, float *__restrict__ part_b /*[grid][4]*/)
@@ -404,13 +426,6 @@ __global__ __launch_bounds__(W) void k_uvmlp_dgrad(const float *__restrict__ gra
         for (int li = D - 1; li >= 1; --li) {
             const float *a_prev = acts + (int64_t)(li - 1) * N * W;
             float *dz_prev = dz + (int64_t)(li - 1) * N * W;
-            float4 pre[UVM_TM / 4];              // A_{li-1} of the tile: the ReLU mask, fetched under the MFMAs
-#pragma unroll
-            for (int p = 0; p < UVM_TM / 4; ++p) {
-                int64_t n = n0 + p * 4 + rg;
-                int64_t nc = n < N ? n : N - 1;
-                pre[p] = *(const float4 *)(a_prev + nc * W + c4 * 4);
-            }
             f32x16 acc[2][2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -421,9 +436,7 @@ __global__ __launch_bounds__(W) void k_uvmlp_dgrad(const float *__restrict__ gra
             const float4 *wp = (const float4 *)(packed + plan.wt_off[li]) + ((size_t)(wave * 2) * 64 + lane);
             const float *arow0 = g + r * STRIDE + 4 * h;
             const float *arow1 = arow0 + 32 * STRIDE;
-            for (int kb = 0; kb < W / 8; ++kb) {
-                float4 b0 = wp[(size_t)kb * (W / 32) * 64];
-                float4 b1 = wp[(size_t)kb * (W / 32) * 64 + 64];
+            auto kstep = [&](int kb, const float4 &b0, const float4 &b1) {
                 float4 a0 = *(const float4 *)(arow0 + kb * 8);
                 float4 a1 = *(const float4 *)(arow1 + kb * 8);
                 const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
@@ -435,6 +448,18 @@ __global__ __launch_bounds__(W) void k_uvmlp_dgrad(const float *__restrict__ gra
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
                 }
+            };
+            constexpr size_t KBS = (size_t)(W / 32) * 64;
+            float4 wa0 = wp[0], wa1 = wp[64], wb0, wb1;
+            for (int kb = 0; kb < W / 8; kb += 2) {
+                const float4 *pb = wp + (size_t)uvm_opaque(kb + 1) * KBS;
+                wb0 = pb[0]; wb1 = pb[64];
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(kb, wa0, wa1);
+                const float4 *pa = wp + (size_t)uvm_opaque(kb + 2 < W / 8 ? kb + 2 : kb) * KBS;
+                wa0 = pa[0]; wa1 = pa[64];
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(kb + 1, wb0, wb1);
             }
             __syncthreads();                     // all fragment reads of dZ_li done
 #pragma unroll
@@ -447,6 +472,13 @@ __global__ __launch_bounds__(W) void k_uvmlp_dgrad(const float *__restrict__ gra
                         int row = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                         g[row * STRIDE + col] = acc[mb][nb][q];
                     }
+            }
+            float4 pre[UVM_TM / 4];              // A_{li-1} of the tile = the ReLU mask (the accumulators are dead by now;
+#pragma unroll                                   // the other resident workgroup's MFMAs cover the latency)
+            for (int p = 0; p < UVM_TM / 4; ++p) {
+                int64_t n = n0 + p * 4 + rg;
+                int64_t nc = n < N ? n : N - 1;
+                pre[p] = *(const float4 *)(a_prev + nc * W + c4 * 4);
             }
             __syncthreads();
 #pragma unroll
@@ -488,12 +520,15 @@ __global__ __launch_bounds__(W) void k_uvmlp_dgrad(const float *__restrict__ gra
 }
 
 // dW[rows x cols] = dZ^T . In over the texel range of this workgroup.  Waves WR x WC, wave tile (32 NI) x (32 NJ).
-template <int WR, int WC, int NI, int NJ>
-__global__ __launch_bounds__(64 * WR * WC) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_uvmlp_wgrad(const float *__restrict__ dz, int ldz, const float *__restrict__ in, int ldin, int in_cols, int64_t N,
-                   int64_t chunk, float *__restrict__ slab, float *__restrict__ bslab)
+// Row strides are compile-time (LDZ = W = rows, LDIN = W or 48) so the operand loads of a whole k-step group hang off two
+// running pointers with immediate offsets; only the last, ragged texel range takes the bounds-checked path.
+template <int WR, int WC, int NI, int NJ, int LDZ, int LDIN, int INCOLS>
+__global__ __launch_bounds__(64 * WR * WC)
+void k_uvmlp_wgrad(const float *__restrict__ dz, const float *__restrict__ in, int64_t N, int64_t chunk, float *__restrict__ slab,
+                   float *__restrict__ bslab)
 {
     constexpr int ROWS = WR * NI * 32, COLS = WC * NJ * 32;
+    static_assert(ROWS == LDZ && COLS >= INCOLS, "workgroup owns the whole gradient");
     constexpr int U = 4;                         // k-steps (2 texels each) per buffer
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -516,25 +551,10 @@ void k_uvmlp_wgrad(const float *__restrict__ dz, int ldz, const float *__restric
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         int cc = col0 + j * 32 + r;
-        bok[j] = cc < in_cols;
-        bcol[j] = bok[j] ? cc : in_cols - 1;
+        bok[j] = cc < INCOLS;
+        bcol[j] = bok[j] ? cc : INCOLS - 1;
     }
-
     float a0[U][NI], b0[U][NJ], a1[U][NI], b1[U][NJ];
-    auto fetch = [&](int64_t t, float (&a)[U][NI], float (&b)[U][NJ]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int64_t tt = t + 2 * u + h;
-            bool ok = tt < t_end;
-            int64_t tc = tt < N ? tt : N - 1;
-            const float *zp = dz + tc * ldz + row0 + r;
-            const float *ip = in + tc * ldin;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) { float v = zp[i * 32]; a[u][i] = ok ? v : 0.f; }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) { float v = ip[bcol[j]]; b[u][j] = bok[j] ? v : 0.f; }
-        }
-    };
     auto mma = [&](const float (&a)[U][NI], const float (&b)[U][NJ]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -543,16 +563,84 @@ void k_uvmlp_wgrad(const float *__restrict__ dz, int ldz, const float *__restric
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
-                if (wc == 0) bs[i] += a[u][i];
+                bs[i] += a[u][i];
             }
         }
     };
-    fetch(t_begin, a0, b0);
-    for (int64_t t = t_begin; t < t_end; t += 4 * U) {
-        fetch(t + 2 * U, a1, b1);                // past-the-end fetches are clamped and zeroed
-        mma(a0, b0);
-        fetch(t + 4 * U, a0, b0);
-        mma(a1, b1);
+    if (t_begin + chunk <= N) {
+        // ---- whole range: no bounds checks.  Three operand buffers of U k-steps: while buffer p feeds the matrix pipe, the
+        // buffer consumed one phase ago is refilled (8 loads after each k-step's 16 MFMAs) and is used one phase later, so a
+        // whole phase (U x 1024 MFMA cycles) covers the memory latency and the waits are vmcnt(one buffer), never 0.
+        const float *zp = dz + (t_begin + h) * LDZ + row0 + r;
+        const float *ip = in + (t_begin + h) * LDIN;
+        float a2[U][NI], b2[U][NJ];
+        auto load_step = [&](int u, float (&a)[U][NI], float (&b)[U][NJ]) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) a[u][i] = zp[u * 2 * LDZ + i * 32];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[u][j] = ip[u * 2 * LDIN + bcol[j]];
+        };
+        auto phase = [&](const float (&a)[U][NI], const float (&b)[U][NJ], float (&na)[U][NI], float (&nb)[U][NJ]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float bv[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bv[j] = (INCOLS == COLS || bok[j]) ? b[u][j] : 0.f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bv[j], acc[i][j], 0, 0, 0);
+                    bs[i] += a[u][i];
+                }
+                load_step(u, na, nb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            zp += 2 * U * LDZ; ip += 2 * U * LDIN;
+        };
+        // prologue: buffers 0 and 1; zp / ip then point at the rows of the buffer to refill next
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_step(u, a0, b0);
+        zp += 2 * U * LDZ; ip += 2 * U * LDIN;
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_step(u, a1, b1);
+        zp += 2 * U * LDZ; ip += 2 * U * LDIN;
+        __builtin_amdgcn_sched_barrier(0);
+        // chunk is a multiple of 3 buffers (48 texels); the refills of the last two phases read (in-bounds or next-range)
+        // rows that are never used: keep them in bounds by stepping back at the end
+        const int rounds = (int)(chunk / (6 * U));
+        const float *zlast = dz + (N - 2 * U + h) * LDZ + row0 + r;     // last whole buffer of the array
+        const float *ilast = in + (N - 2 * U + h) * LDIN;
+        for (int it = 0; it < rounds; ++it) {
+            const bool tail = it + 1 == rounds;
+            phase(a0, b0, a2, b2);
+            if (tail) { zp = zlast; ip = ilast; }
+            phase(a1, b1, a0, b0);
+            if (tail) { zp = zlast; ip = ilast; }
+            phase(a2, b2, a1, b1);
+        }
+    } else {
+        auto fetch = [&](int64_t t, float (&a)[U][NI], float (&b)[U][NJ]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int64_t tt = t + 2 * u + h;
+                bool ok = tt < t_end;
+                int64_t tc = tt < N ? tt : N - 1;
+                const float *zp = dz + tc * LDZ + row0 + r;
+                const float *ip = in + tc * LDIN;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) { float v = zp[i * 32]; a[u][i] = ok ? v : 0.f; }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { float v = ip[bcol[j]]; b[u][j] = bok[j] ? v : 0.f; }
+            }
+        };
+        fetch(t_begin, a0, b0);
+        for (int64_t t = t_begin; t < t_end; t += 4 * U) {
+            fetch(t + 2 * U, a1, b1);            // past-the-end fetches are clamped and zeroed
+            mma(a0, b0);
+            fetch(t + 4 * U, a0, b0);
+            mma(a1, b1);
+        }
     }
     float *sl = slab + (int64_t)blockIdx.x * ROWS * COLS;
 #pragma unroll
@@ -599,18 +687,17 @@ extern "C" int64_t ctx_uvmlp_bwd_ws_bytes(int64_t N, int32_t D, int32_t W)
     if (N <= 0 || D < 1 || D > UVM_MAX_LAYERS || W % 64 != 0 || W > 256) return -1;
     int64_t b = uvm_align((int64_t)D * N * W * 4);                       // dZ
     b += uvm_align((int64_t)UVM_WG_GROUPS * W * (W > 64 ? W : 64) * 4);  // weight-gradient slabs
-    b += uvm_align((int64_t)UVM_WG_GROUPS * W * 4);                      // bias slabs
+    b += uvm_align((int64_t)UVM_WG_GROUPS_EMB * W * 4);                  // bias slabs
     b += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * W * 4);                 // output-layer weight partials
     b += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * 4);                     // output-layer bias partials
     return b;
 }
 
-template <int WR, int WC, int NI, int NJ>
-static void uvm_launch_wgrad(int G, const float *dz, int ldz, const float *in, int ldin, int in_cols, int64_t N, int64_t chunk,
-                             float *slab, float *bslab, hipStream_t s)
+template <int WR, int WC, int NI, int NJ, int LDZ, int LDIN, int INCOLS>
+static void uvm_launch_wgrad(int G, const float *dz, const float *in, int64_t N, int64_t chunk, float *slab, float *bslab, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_uvmlp_wgrad<WR, WC, NI, NJ>), dim3(G), dim3(64 * WR * WC), 0, s, dz, ldz, in, ldin, in_cols, N, chunk,
-                       slab, bslab);
+    hipLaunchKernelGGL((k_uvmlp_wgrad<WR, WC, NI, NJ, LDZ, LDIN, INCOLS>), dim3(G), dim3(64 * WR * WC), 0, s, dz, in, N, chunk, slab,
+                       bslab);
 }
 
 extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, const float *raw, int64_t N, const void *packed,
@@ -632,7 +719,7 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
     char *wp = (char *)ws;
     float *dz = (float *)wp;          wp += uvm_align((int64_t)D * N * W * 4);
     float *slab = (float *)wp;        wp += uvm_align((int64_t)UVM_WG_GROUPS * W * (W > 64 ? W : 64) * 4);
-    float *bslab = (float *)wp;       wp += uvm_align((int64_t)UVM_WG_GROUPS * W * 4);
+    float *bslab = (float *)wp;       wp += uvm_align((int64_t)UVM_WG_GROUPS_EMB * W * 4);
     float *part_w = (float *)wp;      wp += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * W * 4);
     float *part_b = (float *)wp;
 
@@ -656,10 +743,14 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
 
     // ---- phase 2: weight / bias gradients ----
     int64_t chunk = cdiv64(N, UVM_WG_GROUPS);
-    chunk = (chunk + 15) / 16 * 16;              // whole double-buffer rounds (2 x 4 k-steps x 2 texels)
+    chunk = (chunk + 47) / 48 * 48;              // whole rounds of both loop forms (3 buffers x 4 k-steps x 2 texels; 16)
     int G = (int)cdiv64(N, chunk);
+    int64_t chunk_e = cdiv64(N, UVM_WG_GROUPS_EMB);
+    chunk_e = (chunk_e + 47) / 48 * 48;
+    int Ge = (int)cdiv64(N, chunk_e);
     const float *emb = saved;
     const float *acts = saved + N * UVM_EPAD;
+    static const int wg8 = [] { const char *e = getenv("CTX_UVM_WG8"); return e ? atoi(e) : 0; }();
     for (int li = D - 1; li >= 0; --li) {
         const float *dzl = dz + (int64_t)li * N * W;
         const int kin = li == 0 ? input_ch : (li == skip + 1 ? input_ch + W : W);
@@ -667,9 +758,11 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
         const bool has_hid = li != 0;
         if (has_hid) {
             const float *in = acts + (int64_t)(li - 1) * N * W;
-            if (W == 256) uvm_launch_wgrad<2, 2, 4, 4>(G, dzl, W, in, W, W, N, chunk, slab, bslab, s);
-            else if (W == 128) uvm_launch_wgrad<2, 2, 2, 2>(G, dzl, W, in, W, W, N, chunk, slab, bslab, s);
-            else uvm_launch_wgrad<2, 2, 1, 1>(G, dzl, W, in, W, W, N, chunk, slab, bslab, s);
+            if (W == 256) {
+                if (wg8) uvm_launch_wgrad<2, 4, 4, 2, 256, 256, 256>(G, dzl, in, N, chunk, slab, bslab, s);
+                else uvm_launch_wgrad<2, 2, 4, 4, 256, 256, 256>(G, dzl, in, N, chunk, slab, bslab, s);
+            } else if (W == 128) uvm_launch_wgrad<2, 2, 2, 2, 128, 128, 128>(G, dzl, in, N, chunk, slab, bslab, s);
+            else uvm_launch_wgrad<2, 2, 1, 1, 64, 64, 64>(G, dzl, in, N, chunk, slab, bslab, s);
             CTX_CHECK_LAUNCH("uvmlp_wgrad");
             hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * W, 256)), dim3(256), 0, s, slab, G, (int64_t)W * W, W, W, W, gws[li], kin,
                                has_emb ? input_ch : 0);
@@ -677,13 +770,13 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
         }
         if (has_emb) {
             float *bsl = has_hid ? nullptr : bslab;
-            if (W == 256) uvm_launch_wgrad<4, 1, 2, 2>(G, dzl, W, emb, UVM_EPAD, UVM_EPAD, N, chunk, slab, bsl, s);
-            else if (W == 128) uvm_launch_wgrad<2, 1, 2, 2>(G, dzl, W, emb, UVM_EPAD, UVM_EPAD, N, chunk, slab, bsl, s);
-            else uvm_launch_wgrad<1, 1, 2, 2>(G, dzl, W, emb, UVM_EPAD, UVM_EPAD, N, chunk, slab, bsl, s);
+            if (W == 256) uvm_launch_wgrad<4, 1, 2, 2, 256, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
+            else if (W == 128) uvm_launch_wgrad<2, 1, 2, 2, 128, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
+            else uvm_launch_wgrad<1, 1, 2, 2, 64, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
             CTX_CHECK_LAUNCH("uvmlp_wgrad_emb");
-            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * 64, 256)), dim3(256), 0, s, slab, G, (int64_t)W * 64, W, 64, input_ch, gws[li], kin, 0);
+            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * 64, 256)), dim3(256), 0, s, slab, Ge, (int64_t)W * 64, W, 64, input_ch, gws[li], kin, 0);
             if (!has_hid)
-                hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W, 256)), dim3(256), 0, s, bslab, G, (int64_t)W, 1, W, W, gbs[li], W, 0);
+                hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W, 256)), dim3(256), 0, s, bslab, Ge, (int64_t)W, 1, W, W, gbs[li], W, 0);
         }
         CTX_CHECK_LAUNCH("uvmlp_wgrad_reduce");
     }

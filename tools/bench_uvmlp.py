@@ -35,6 +35,7 @@ state = {}
 
 
 def fwd():
+    state.clear()                                   # one set of saved activations alive at a time
     state['tex'], state['raw'] = net.texture_map(res)
 
 
