@@ -236,6 +236,7 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
         }
         __syncthreads();   // everyone has finished reading this layer's input
         const float *bias = packed + ly.b_off;
+        unsigned long long relu_bits = 0;   // bit (nb*2+mb)*16+q of this lane: its accumulator element is > 0
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             int col = wave * 64 + nb * 32 + r;
@@ -246,8 +247,13 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
                 for (int q = 0; q < 16; ++q) {
                     int row = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                     float v = acc[mb][nb][q] + bv;
+                    relu_bits |= (unsigned long long)(v > 0.f) << ((nb * 2 + mb) * 16 + q);
                     act[row * STRIDE + UVM_EPAD + col] = v > 0.f ? v : 0.f;
                 }
+        }
+        if (saved) {   // the ReLU pattern in the accumulator layout the backward chain's tiles have: [layer][tile][thread] u64
+            unsigned long long *mk = (unsigned long long *)(saved + N * (int64_t)(UVM_EPAD + plan.n_hidden * W));
+            mk[((int64_t)li * gridDim.x + blockIdx.x) * W + tid] = relu_bits;
         }
         __syncthreads();
         if (saved) {   // post-ReLU activations [layer][texel][W], whole rows per texel
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
 extern "C" int64_t ctx_uvmlp_saved_bytes(int64_t N, int32_t D, int32_t W)
 {
     if (N <= 0 || D < 1 || D > UVM_MAX_LAYERS || W % 64 != 0 || W > 256) return -1;
-    return N * (int64_t)(UVM_EPAD + D * W) * 4;
+    return N * (int64_t)(UVM_EPAD + D * W) * 4 + (int64_t)D * cdiv64(N, UVM_TM) * W * 8;   // + ReLU bit masks
 }
 
 extern "C" int32_t ctx_uvmlp_fwd_save(const float *uv, const float *emb, int64_t N, int32_t res, const void *packed, int32_t D, int32_t W,
@@ -363,6 +369,7 @@ __global__ __launch_bounds__(W, 2) void k_uvmlp_dgrad(const float *__restrict__ 
     const int c4 = tid % C4N, rg = tid / C4N;
     const int D = plan.n_hidden;
     const float *acts = saved + N * UVM_EPAD;
+    const unsigned long long *masks = (const unsigned long long *)(saved + N * (int64_t)(UVM_EPAD + D * W));
 
     float wo[4][4], gwo[4][4];
 #pragma unroll
@@ -424,8 +431,8 @@ __global__ __launch_bounds__(W, 2) void k_uvmlp_dgrad(const float *__restrict__ 
         __syncthreads();
         // ---- hidden layers, last to second ------------------------------------------------------
         for (int li = D - 1; li >= 1; --li) {
-            const float *a_prev = acts + (int64_t)(li - 1) * N * W;
             float *dz_prev = dz + (int64_t)(li - 1) * N * W;
+            const unsigned long long relu_bits = masks[((int64_t)(li - 1) * ntiles + tile) * W + tid];
             f32x16 acc[2][2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -461,7 +468,8 @@ __global__ __launch_bounds__(W, 2) void k_uvmlp_dgrad(const float *__restrict__ 
                 __builtin_amdgcn_sched_barrier(0);
                 kstep(kb + 1, wb0, wb1);
             }
-            __syncthreads();                     // all fragment reads of dZ_li done
+            __syncthreads();                     // all fragment reads of dZ_li (and the row copies of it below) are done
+            // dZ_{li-1} = dA_{li-1} * relu'(layer li-1): the forward left the pattern in this very accumulator layout
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 int col = wave * 64 + nb * 32 + r;
@@ -470,31 +478,20 @@ __global__ __launch_bounds__(W, 2) void k_uvmlp_dgrad(const float *__restrict__ 
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         int row = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                        g[row * STRIDE + col] = acc[mb][nb][q];
+                        bool on = (relu_bits >> ((nb * 2 + mb) * 16 + q)) & 1ull;
+                        g[row * STRIDE + col] = on ? acc[mb][nb][q] : 0.f;
                     }
             }
-            float4 pre[UVM_TM / 4];              // A_{li-1} of the tile = the ReLU mask (the accumulators are dead by now;
-#pragma unroll                                   // the other resident workgroup's MFMAs cover the latency)
-            for (int p = 0; p < UVM_TM / 4; ++p) {
-                int64_t n = n0 + p * 4 + rg;
-                int64_t nc = n < N ? n : N - 1;
-                pre[p] = *(const float4 *)(a_prev + nc * W + c4 * 4);
-            }
             __syncthreads();
-#pragma unroll
+            // whole rows of dZ_{li-1} to HBM; the next layer's fragment reads of g run alongside (both only read)
+#pragma unroll 4
             for (int p = 0; p < UVM_TM / 4; ++p) {
                 int t = p * 4 + rg;
                 int64_t n = n0 + t;
-                float4 v = *(const float4 *)(g + t * STRIDE + c4 * 4);
-                v.x = pre[p].x > 0.f ? v.x : 0.f;
-                v.y = pre[p].y > 0.f ? v.y : 0.f;
-                v.z = pre[p].z > 0.f ? v.z : 0.f;
-                v.w = pre[p].w > 0.f ? v.w : 0.f;
-                *(float4 *)(g + t * STRIDE + c4 * 4) = v;
-                if (n < N) *(float4 *)(dz_prev + n * W + c4 * 4) = v;
+                if (n < N) *(float4 *)(dz_prev + n * W + c4 * 4) = *(const float4 *)(g + t * STRIDE + c4 * 4);
             }
-            __syncthreads();
         }
+        __syncthreads();                         // the last row copies read g before the next tile overwrites it
     }
     // ---- output-layer gradients of this workgroup: fold the 4 row groups, one partial row per channel ----
     __syncthreads();
@@ -661,23 +658,39 @@ void k_uvmlp_wgrad(const float *__restrict__ dz, const float *__restrict__ in, i
     }
 }
 
-// out[n][col_off + k] = sum_g slab[g][n][k]  (fixed order), k < out_cols.
-__global__ void k_uvm_reduce(const float *__restrict__ slab, int G, int64_t stride, int rows, int cols_pad, int out_cols,
-                             float *__restrict__ out, int ld_out, int col_off)
+// out[n][col_off + k] = sum_g slab[g][n][k]  (fixed order), k < out_cols.  One thread per (4 columns, quarter of the groups):
+// 16-byte loads, the four quarters folded through LDS in a fixed order.  cols_pad % 4 == 0.
+__global__ __launch_bounds__(256) void k_uvm_reduce(const float *__restrict__ slab, int G, int64_t stride, int rows, int cols_pad,
+                                                    int out_cols, float *__restrict__ out, int ld_out, int col_off)
 {
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= rows * cols_pad) return;
-    int n = idx / cols_pad, k = idx % cols_pad;
-    if (k >= out_cols) return;
-    const float *p = slab + idx;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int gi = 0;
-    for (; gi + 4 <= G; gi += 4) {
-        s0 += p[(gi + 0) * stride]; s1 += p[(gi + 1) * stride];
-        s2 += p[(gi + 2) * stride]; s3 += p[(gi + 3) * stride];
+    __shared__ float4 part[4][64];
+    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int idx4 = blockIdx.x * 64 + l;                    // float4 index within rows x cols_pad
+    const int total4 = rows * cols_pad / 4;
+    const int gq = (G + 3) / 4;
+    const int g0 = q * gq, g1 = (g0 + gq < G ? g0 + gq : G);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (idx4 < total4) {
+        const float4 *p = (const float4 *)slab + idx4;
+        const int64_t st4 = stride / 4;
+        int gi = g0;
+        for (; gi + 2 <= g1; gi += 2) {
+            float4 a = p[gi * st4], b = p[(gi + 1) * st4];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (gi < g1) { float4 a = p[gi * st4]; s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
     }
-    for (; gi < G; ++gi) s0 += p[gi * stride];
-    out[(int64_t)n * ld_out + col_off + k] = (s0 + s1) + (s2 + s3);
+    part[q][l] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (q == 0 && idx4 < total4) {
+        float4 a = part[0][l], b = part[1][l], c = part[2][l], d = part[3][l];
+        const float v[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+        const int n = idx4 * 4 / cols_pad, k = idx4 * 4 % cols_pad;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j < out_cols) out[(int64_t)n * ld_out + col_off + k + j] = v[j];
+    }
 }
 
 static inline int64_t uvm_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -736,7 +749,7 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
         hipLaunchKernelGGL(k_uvmlp_dgrad<64>, dim3(dg), dim3(64), lds, s, grad_raw, grad_tex, raw, N, pk, p, saved, dz, part_w, part_b);
     }
     CTX_CHECK_LAUNCH("uvmlp_dgrad");
-    hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(output_ch * W, 256)), dim3(256), 0, s, part_w, dg, (int64_t)4 * W, output_ch, W, W,
+    hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(output_ch * W / 4, 64)), dim3(256), 0, s, part_w, dg, (int64_t)4 * W, output_ch, W, W,
                        gws[D], W, 0);
     hipLaunchKernelGGL(k_uvm_reduce, dim3(1), dim3(256), 0, s, part_b, dg, (int64_t)4, 1, 4, output_ch, gbs[D], 4, 0);
     CTX_CHECK_LAUNCH("uvmlp_reduce_out");
@@ -764,9 +777,9 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
             } else if (W == 128) uvm_launch_wgrad<2, 2, 2, 2, 128, 128, 128>(G, dzl, in, N, chunk, slab, bslab, s);
             else uvm_launch_wgrad<2, 2, 1, 1, 64, 64, 64>(G, dzl, in, N, chunk, slab, bslab, s);
             CTX_CHECK_LAUNCH("uvmlp_wgrad");
-            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * W, 256)), dim3(256), 0, s, slab, G, (int64_t)W * W, W, W, W, gws[li], kin,
+            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * W / 4, 64)), dim3(256), 0, s, slab, G, (int64_t)W * W, W, W, W, gws[li], kin,
                                has_emb ? input_ch : 0);
-            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W, 256)), dim3(256), 0, s, bslab, G, (int64_t)W, 1, W, W, gbs[li], W, 0);
+            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W / 4, 64)), dim3(256), 0, s, bslab, G, (int64_t)W, 1, W, W, gbs[li], W, 0);
         }
         if (has_emb) {
             float *bsl = has_hid ? nullptr : bslab;
@@ -774,9 +787,9 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
             else if (W == 128) uvm_launch_wgrad<2, 1, 2, 2, 128, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
             else uvm_launch_wgrad<1, 1, 2, 2, 64, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
             CTX_CHECK_LAUNCH("uvmlp_wgrad_emb");
-            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * 64, 256)), dim3(256), 0, s, slab, Ge, (int64_t)W * 64, W, 64, input_ch, gws[li], kin, 0);
+            hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * 64 / 4, 64)), dim3(256), 0, s, slab, Ge, (int64_t)W * 64, W, 64, input_ch, gws[li], kin, 0);
             if (!has_hid)
-                hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W, 256)), dim3(256), 0, s, bslab, Ge, (int64_t)W, 1, W, W, gbs[li], W, 0);
+                hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W / 4, 64)), dim3(256), 0, s, bslab, Ge, (int64_t)W, 1, W, W, gbs[li], W, 0);
         }
         CTX_CHECK_LAUNCH("uvmlp_wgrad_reduce");
     }

@@ -50,12 +50,20 @@ class _UvMlpFn(torch.autograd.Function):
         blob = net.packed()
         dev = blob.device
         Lf = (net.input_ch // 2 - 1) // 2
+        # the activation store (8.8 GB for the 1024^2 atlas) is kept by the module and handed out to one forward at a time;
+        # allocating it per call makes the caching allocator split and re-malloc multi-GB blocks
+        nbytes = lib.ctx_uvmlp_saved_bytes(N, net.D, net.W)
+        saved = net._saved_pool if (net._saved_pool is not None and net._saved_pool.numel() == nbytes
+                                    and net._saved_pool.device == dev) else None
+        net._saved_pool = None
+        if saved is None:
+            saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         raw = torch.empty(N, net.output_ch, device=dev)
         tex = torch.empty(net.output_ch, N, device=dev) if want_tex else None
-        saved = torch.empty(lib.ctx_uvmlp_saved_bytes(N, net.D, net.W), dtype=torch.uint8, device=dev)
         L.check(lib.ctx_uvmlp_fwd_save(L.ptr(uv), L.ptr(emb), N, res, L.ptr(blob), net.D, net.W, Lf, net.output_ch,
                                        net.skips[0], L.ptr(raw), L.ptr(tex), L.ptr(saved), L.stream()))
-        ctx.net, ctx.N, ctx.saved_acts, ctx.raw, ctx.blob = net, N, saved, raw, blob
+        ctx.net, ctx.N, ctx.saved_acts, ctx.blob = net, N, saved, blob
+        ctx.save_for_backward(raw)          # an output: kept through save_for_backward so the graph holds no reference cycle
         ctx.set_materialize_grads(False)
         return (raw, tex) if want_tex else raw
 
@@ -63,19 +71,24 @@ class _UvMlpFn(torch.autograd.Function):
     def backward(ctx, g_raw, g_tex=None):
         lib = L.load()
         net, N = ctx.net, ctx.N
-        dev = ctx.raw.device
+        raw, = ctx.saved_tensors
+        dev = raw.device
         layers = list(net.pts_linears) + [net.output_linear]
         gws = [torch.empty_like(l.weight) for l in layers]
         gbs = [torch.empty_like(l.bias) for l in layers]
-        ws = torch.empty(lib.ctx_uvmlp_bwd_ws_bytes(N, net.D, net.W), dtype=torch.uint8, device=dev)
+        wsb = lib.ctx_uvmlp_bwd_ws_bytes(N, net.D, net.W)
+        if net._bwd_ws is None or net._bwd_ws.numel() != wsb or net._bwd_ws.device != dev:
+            net._bwd_ws = None
+            net._bwd_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)     # scratch, stream-ordered: reusable
+        ws = net._bwd_ws
         gwp = (C.c_void_p * len(gws))(*[L.ptr(g).value for g in gws])
         gbp = (C.c_void_p * len(gbs))(*[L.ptr(g).value for g in gbs])
         g_raw = None if g_raw is None else L.f32c(g_raw)
         g_tex = None if g_tex is None else L.f32c(g_tex)
         Lf = (net.input_ch // 2 - 1) // 2
-        L.check(lib.ctx_uvmlp_bwd(L.ptr(g_raw), L.ptr(g_tex), L.ptr(ctx.raw), N, L.ptr(ctx.blob), net.D, net.W, Lf,
+        L.check(lib.ctx_uvmlp_bwd(L.ptr(g_raw), L.ptr(g_tex), L.ptr(raw), N, L.ptr(ctx.blob), net.D, net.W, Lf,
                                   net.output_ch, net.skips[0], L.ptr(ctx.saved_acts), L.ptr(ws), gwp, gbp, L.stream()))
-        ctx.saved_acts = None
+        net._saved_pool, ctx.saved_acts = ctx.saved_acts, None          # back to the module for the next forward
         grads = []
         for w, b in zip(gws, gbs):
             grads += [w, b]
@@ -95,6 +108,8 @@ class NeRF2D(nn.Module):
         nn.init.kaiming_normal_(self.output_linear.weight, mode='fan_in', nonlinearity='relu')
         self._packed = None
         self._packed_version = None
+        self._saved_pool = None      # activation store of the training forward, reused across iterations
+        self._bwd_ws = None          # backward scratch
 
     # -- weight packing (cached; invalidated by in-place parameter updates via _version) --------------
     def _version(self):

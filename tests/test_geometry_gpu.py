@@ -311,7 +311,7 @@ def _field_bwd_abi(net, uv, c_raw, res=0, c_tex=None):
     gbp = (C.c_void_p * (D + 1))(*[L.ptr(t).value for t in gbs])
     L.check(lib.ctx_uvmlp_bwd(L.ptr(c_raw), L.ptr(c_tex), L.ptr(raw), N, L.ptr(blob), D, W, 10, 3, 4, L.ptr(saved), L.ptr(ws), gwp, gbp,
                               L.stream()))
-    return gws, gbs, saved[N * 48:].reshape(D, N, W)
+    return gws, gbs, saved[N * 48:N * 48 + D * N * W].reshape(D, N, W)     # (the ReLU bit masks follow)
 
 
 @pytest.mark.parametrize("W,N", [(64, 1), (128, 517), (256, 4133), (256, 64 * 300), (256, 64 * 700 + 5)])
