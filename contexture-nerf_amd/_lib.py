@@ -36,10 +36,10 @@ SIGNATURES = {
     "ctx_uvmlp_packed_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "ctx_uvmlp_pack": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ctx_uvmlp_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "ctx_uvmlp_saved_bytes": (_i64, [_i64, _i32, _i32]),
-    "ctx_uvmlp_fwd_save": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ctx_uvmlp_saved_bytes": (_i64, [_i64, _i32, _i32, _i32]),
+    "ctx_uvmlp_fwd_save": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ctx_uvmlp_bwd_ws_bytes": (_i64, [_i64, _i32, _i32]),
-    "ctx_uvmlp_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ctx_uvmlp_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ctx_get_rays": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "ctx_raymarch_composite_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctx_unet_create": (_vp, [_vp]),

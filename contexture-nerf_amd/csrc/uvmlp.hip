@@ -15,7 +15,8 @@
 #include <stdlib.h>
 
 #define UVM_MAX_LAYERS 16
-#define UVM_EPAD 48       // padded embedding width (42 -> 48)
+#define UVM_EPAD 48       // padded embedding width of the 2-D field (42 -> 48)
+#define UVM_EPAD3 64      // ... of the 3-D field (63 -> 64); the plan carries the one in use
 #define UVM_TM 64         // texels per workgroup
 
 // Weight fragments of the NEXT k-block are fetched while the current one feeds the matrix pipe.  hipcc re-materialises a plain
@@ -37,7 +38,9 @@ struct UvmLayer {
 struct UvmPlan {
     int n_hidden;            // D
     int W;
-    int in_ch;               // 2*(1+2L)
+    int in_ch;               // dims*(1+2L)
+    int epad;                // in_ch padded: 48 or 64
+    int dims;                // input dimensionality (2: uv, 3: xyz); set by the forward entry
     int out_ch;
     int64_t out_w_off, out_b_off;
     UvmLayer layer[UVM_MAX_LAYERS];
@@ -46,14 +49,15 @@ struct UvmPlan {
 
 static int uvm_build_plan(int D, int W, int input_ch, int output_ch, int skip, UvmPlan &p, int64_t &total)
 {
-    if (D < 1 || D > UVM_MAX_LAYERS || W % 64 != 0 || W > 256 || input_ch > UVM_EPAD || output_ch > 4) return -1;
-    p.n_hidden = D; p.W = W; p.in_ch = input_ch; p.out_ch = output_ch;
+    if (D < 1 || D > UVM_MAX_LAYERS || W % 64 != 0 || W > 256 || input_ch < 1 || input_ch > UVM_EPAD3 || output_ch < 1 || output_ch > 4) return -1;
+    const int EP = input_ch <= UVM_EPAD ? UVM_EPAD : UVM_EPAD3;
+    p.n_hidden = D; p.W = W; p.in_ch = input_ch; p.out_ch = output_ch; p.epad = EP; p.dims = 2;
     int64_t off = 0;
     for (int i = 0; i < D; ++i) {
         UvmLayer &l = p.layer[i];
-        if (i == 0) { l.col0 = 0; l.kp = UVM_EPAD; }
-        else if (i == skip + 1) { l.col0 = 0; l.kp = UVM_EPAD + W; }
-        else { l.col0 = UVM_EPAD; l.kp = W; }
+        if (i == 0) { l.col0 = 0; l.kp = EP; }
+        else if (i == skip + 1) { l.col0 = 0; l.kp = EP + W; }
+        else { l.col0 = EP; l.kp = W; }
         l.w_off = off; off += (int64_t)l.kp * W;
         l.b_off = off; off += W;
     }
@@ -75,7 +79,7 @@ extern "C" int64_t ctx_uvmlp_packed_bytes(int32_t D, int32_t W, int32_t input_ch
 // src: nn.Linear weight [W][kin]; dst packed [(kb*(W/32)+nb)*64+lane][4] with
 // lane=(r,h): value j = weight[nb*32+r][map(kb*8+4h+j)].
 __global__ void k_uvm_pack(const float *__restrict__ w, const float *__restrict__ b, int W, int kin, int kp,
-                           int in_ch, int mode /*0 first,1 skip,2 plain*/, float *__restrict__ dw, float *__restrict__ db)
+                           int in_ch, int epad, int mode /*0 first,1 skip,2 plain*/, float *__restrict__ dw, float *__restrict__ db)
 {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t total = (int64_t)kp * W;
@@ -91,7 +95,7 @@ __global__ void k_uvm_pack(const float *__restrict__ w, const float *__restrict_
         int src_k;
         if (mode == 2) src_k = k;
         else if (mode == 0) src_k = k < in_ch ? k : -1;
-        else src_k = k < in_ch ? k : (k < UVM_EPAD ? -1 : k - UVM_EPAD + in_ch);
+        else src_k = k < in_ch ? k : (k < epad ? -1 : k - epad + in_ch);
         dw[idx] = (src_k >= 0 && src_k < kin) ? w[(int64_t)n * kin + src_k] : 0.0f;
     }
     if (idx < W) db[idx] = b[idx];
@@ -136,7 +140,7 @@ extern "C" int32_t ctx_uvmlp_pack(const float *const *ws, const float *const *bs
         int kin = i == 0 ? input_ch : (i == skip + 1 ? input_ch + W : W);
         int64_t n = (int64_t)p.layer[i].kp * W;
         hipLaunchKernelGGL(k_uvm_pack, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, ws[i], bs[i], W, kin, p.layer[i].kp,
-                           input_ch, mode, dst + p.layer[i].w_off, dst + p.layer[i].b_off);
+                           input_ch, p.epad, mode, dst + p.layer[i].w_off, dst + p.layer[i].b_off);
         if (i >= 1)
             hipLaunchKernelGGL(k_uvm_pack_t, dim3((unsigned)cdiv64((int64_t)W * W, 256)), dim3(256), 0, s, ws[i], W, kin,
                                i == skip + 1 ? input_ch : 0, dst + p.wt_off[i]);
@@ -147,12 +151,12 @@ extern "C" int32_t ctx_uvmlp_pack(const float *const *ws, const float *const *bs
     return CTX_OK;
 }
 
-template <int W>
+template <int W, int EP>
 __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, const float *__restrict__ emb, int64_t N, int res, int L,
                                                  const float *__restrict__ packed, UvmPlan plan,
                                                  float *__restrict__ raw, float *__restrict__ tex, float *__restrict__ saved)
 {
-    constexpr int STRIDE = UVM_EPAD + W + 4;   // 308 for W=256: 4 x odd -> conflict-free ds_read_b128 rows
+    constexpr int STRIDE = EP + W + 4;   // 308 / 324 for W=256: 4 x odd -> conflict-free ds_read_b128 rows
     static_assert((STRIDE / 4) % 2 == 1, "row stride must be 4 x odd");
     extern __shared__ __attribute__((aligned(16))) float act[];   // [UVM_TM][STRIDE]
     const int tid = threadIdx.x;
@@ -164,34 +168,36 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
     {
         int row = tid & 63;
         int64_t n = n0 + row;
-        float u = 0.f, v = 0.f;
+        const int d = plan.dims;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
         if (n < N && !emb) {
-            if (uv) { u = uv[n * 2 + 0]; v = uv[n * 2 + 1]; }
+            if (uv) { x0 = uv[n * d + 0]; x1 = uv[n * d + 1]; if (d > 2) x2 = uv[n * d + 2]; }
             else {
                 // torch.linspace(0,1,res): start + i*step for the first half, end - (res-1-i)*step after
                 int i = (int)(n / res), j = (int)(n % res);
                 float step = 1.0f / (float)(res - 1);
-                u = (j < res / 2) ? (float)j * step : 1.0f - (float)(res - 1 - j) * step;
-                v = (i < res / 2) ? (float)i * step : 1.0f - (float)(res - 1 - i) * step;
+                x0 = (j < res / 2) ? (float)j * step : 1.0f - (float)(res - 1 - j) * step;
+                x1 = (i < res / 2) ? (float)i * step : 1.0f - (float)(res - 1 - i) * step;
             }
         }
-        for (int e = wave; e < UVM_EPAD; e += W / 64) {
+        for (int e = wave; e < EP; e += W / 64) {
             float val = 0.f;
             if (emb) val = (e < plan.in_ch && n < N) ? emb[n * plan.in_ch + e] : 0.f;
-            else if (e < 2) val = e == 0 ? u : v;
-            else if (e < 2 + 4 * L) {
-                int l = (e - 2) >> 2, q = (e - 2) & 3;
-                float a = ((q & 1) ? v : u) * (float)(1 << l);
-                val = (q & 2) ? cosf(a) : sinf(a);
+            else if (e < d) val = e == 0 ? x0 : (e == 1 ? x1 : x2);
+            else if (e < d * (1 + 2 * L)) {
+                int l = (e - d) / (2 * d), q = (e - d) % (2 * d);      // [sin(2^l x) (d), cos(2^l x) (d)] per frequency
+                int c = q % d;
+                float a = (c == 0 ? x0 : (c == 1 ? x1 : x2)) * (float)(1 << l);
+                val = (q >= d) ? cosf(a) : sinf(a);
             }
             act[row * STRIDE + e] = val;
         }
     }
     __syncthreads();
     if (saved) {   // training: keep the (padded) embedding for the weight gradients of layer 0 and the skip layer
-        for (int i = tid; i < UVM_TM * (UVM_EPAD / 4); i += W) {
-            int row = i / (UVM_EPAD / 4), c4 = i % (UVM_EPAD / 4);
-            if (n0 + row < N) *(float4 *)(saved + (n0 + row) * UVM_EPAD + c4 * 4) = *(const float4 *)(act + row * STRIDE + c4 * 4);
+        for (int i = tid; i < UVM_TM * (EP / 4); i += W) {
+            int row = i / (EP / 4), c4 = i % (EP / 4);
+            if (n0 + row < N) *(float4 *)(saved + (n0 + row) * EP + c4 * 4) = *(const float4 *)(act + row * STRIDE + c4 * 4);
         }
     }
 
@@ -248,19 +254,19 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
                     int row = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                     float v = acc[mb][nb][q] + bv;
                     relu_bits |= (unsigned long long)(v > 0.f) << ((nb * 2 + mb) * 16 + q);
-                    act[row * STRIDE + UVM_EPAD + col] = v > 0.f ? v : 0.f;
+                    act[row * STRIDE + EP + col] = v > 0.f ? v : 0.f;
                 }
         }
         if (saved) {   // the ReLU pattern in the accumulator layout the backward chain's tiles have: [layer][tile][thread] u64
-            unsigned long long *mk = (unsigned long long *)(saved + N * (int64_t)(UVM_EPAD + plan.n_hidden * W));
+            unsigned long long *mk = (unsigned long long *)(saved + N * (int64_t)(EP + plan.n_hidden * W));
             mk[((int64_t)li * gridDim.x + blockIdx.x) * W + tid] = relu_bits;
         }
         __syncthreads();
         if (saved) {   // post-ReLU activations [layer][texel][W], whole rows per texel
-            float *dst = saved + N * UVM_EPAD + (int64_t)li * N * W;
+            float *dst = saved + N * EP + (int64_t)li * N * W;
             for (int i = tid; i < UVM_TM * (W / 4); i += W) {
                 int row = i / (W / 4), c4 = i % (W / 4);
-                if (n0 + row < N) *(float4 *)(dst + (n0 + row) * W + c4 * 4) = *(const float4 *)(act + row * STRIDE + UVM_EPAD + c4 * 4);
+                if (n0 + row < N) *(float4 *)(dst + (n0 + row) * W + c4 * 4) = *(const float4 *)(act + row * STRIDE + EP + c4 * 4);
             }
         }
     }
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
     {
         constexpr int PARTS = W / 64;            // threads per texel
         int row = tid / PARTS, part = tid % PARTS;
-        const float *a = act + row * STRIDE + UVM_EPAD + part * 64;
+        const float *a = act + row * STRIDE + EP + part * 64;
         const float *ow = packed + plan.out_w_off + part * 64;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < 64; ++k) {
@@ -292,38 +298,43 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
     }
 }
 
-extern "C" int64_t ctx_uvmlp_saved_bytes(int64_t N, int32_t D, int32_t W)
+static inline int uvm_epad(int input_ch) { return input_ch <= UVM_EPAD ? UVM_EPAD : UVM_EPAD3; }
+
+extern "C" int64_t ctx_uvmlp_saved_bytes(int64_t N, int32_t D, int32_t W, int32_t input_ch)
 {
-    if (N <= 0 || D < 1 || D > UVM_MAX_LAYERS || W % 64 != 0 || W > 256) return -1;
-    return N * (int64_t)(UVM_EPAD + D * W) * 4 + (int64_t)D * cdiv64(N, UVM_TM) * W * 8;   // + ReLU bit masks
+    if (N <= 0 || D < 1 || D > UVM_MAX_LAYERS || W % 64 != 0 || W > 256 || input_ch < 1 || input_ch > UVM_EPAD3) return -1;
+    return N * (int64_t)(uvm_epad(input_ch) + D * W) * 4 + (int64_t)D * cdiv64(N, UVM_TM) * W * 8;   // + ReLU bit masks
 }
 
 extern "C" int32_t ctx_uvmlp_fwd_save(const float *uv, const float *emb, int64_t N, int32_t res, const void *packed, int32_t D, int32_t W,
-                                      int32_t L, int32_t output_ch, int32_t skip, float *raw, float *tex_chw, void *saved_v,
+                                      int32_t dims, int32_t L, int32_t output_ch, int32_t skip, float *raw, float *tex_chw, void *saved_v,
                                       ctx_stream_t stream)
 {
     float *saved = (float *)saved_v;
     UvmPlan p; int64_t total = 0;
     CTX_REQUIRE(packed && raw && N > 0, "uvmlp_fwd: bad args");
-    CTX_REQUIRE(uv || emb || (res > 1 && (int64_t)res * res == N), "uvmlp_fwd: uv == NULL needs N == res*res (N=%lld res=%d)", (long long)N, res);
-    int input_ch = 2 * (1 + 2 * L);
+    CTX_REQUIRE(dims == 2 || dims == 3, "uvmlp_fwd: dims=%d (2: uv, 3: xyz)", dims);
+    CTX_REQUIRE(uv || emb || (dims == 2 && res > 1 && (int64_t)res * res == N),
+                "uvmlp_fwd: no inputs needs dims == 2 and N == res*res (N=%lld res=%d)", (long long)N, res);
+    int input_ch = dims * (1 + 2 * L);
     CTX_REQUIRE(uvm_build_plan(D, W, input_ch, output_ch, skip, p, total) == 0,
-                "uvmlp_fwd: unsupported D=%d W=%d L=%d output_ch=%d", D, W, L, output_ch);
+                "uvmlp_fwd: unsupported D=%d W=%d dims=%d L=%d output_ch=%d", D, W, dims, L, output_ch);
+    p.dims = dims;
     hipStream_t s = (hipStream_t)stream;
     unsigned grid = (unsigned)cdiv64(N, UVM_TM);
-    size_t lds = (size_t)UVM_TM * (UVM_EPAD + W + 4) * 4;
+    size_t lds = (size_t)UVM_TM * (p.epad + W + 4) * 4;
     const float *pk = (const float *)packed;
-    if (W == 256) {
-        (void)hipFuncSetAttribute((const void *)k_uvmlp_fwd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_uvmlp_fwd<256>, dim3(grid), dim3(256), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw, saved);
-    } else if (W == 128) {
-        hipLaunchKernelGGL(k_uvmlp_fwd<128>, dim3(grid), dim3(128), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw, saved);
-    } else if (W == 64) {
-        hipLaunchKernelGGL(k_uvmlp_fwd<64>, dim3(grid), dim3(64), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw, saved);
+#define UVM_FWD(WW, EE)                                                                                                     \
+    do {                                                                                                                    \
+        (void)hipFuncSetAttribute((const void *)k_uvmlp_fwd<WW, EE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_uvmlp_fwd<WW, EE>), dim3(grid), dim3(WW), lds, s, uv, emb, N, res, L, pk, p, raw, tex_chw, saved); \
+    } while (0)
+    if (p.epad == UVM_EPAD) {
+        if (W == 256) UVM_FWD(256, UVM_EPAD); else if (W == 128) UVM_FWD(128, UVM_EPAD); else UVM_FWD(64, UVM_EPAD);
     } else {
-        ctx_set_error("uvmlp_fwd: W=%d unsupported (64/128/256)", W);
-        return CTX_E_ARG;
+        if (W == 256) UVM_FWD(256, UVM_EPAD3); else if (W == 128) UVM_FWD(128, UVM_EPAD3); else UVM_FWD(64, UVM_EPAD3);
     }
+#undef UVM_FWD
     CTX_CHECK_LAUNCH("uvmlp_fwd");
     return CTX_OK;
 }
@@ -332,7 +343,7 @@ extern "C" int32_t ctx_uvmlp_fwd(const float *uv, const float *emb, int64_t N, i
                                  int32_t L, int32_t output_ch, int32_t skip, float *raw, float *tex_chw,
                                  ctx_stream_t stream)
 {
-    return ctx_uvmlp_fwd_save(uv, emb, N, res, packed, D, W, L, output_ch, skip, raw, tex_chw, nullptr, stream);
+    return ctx_uvmlp_fwd_save(uv, emb, N, res, packed, D, W, 2, L, output_ch, skip, raw, tex_chw, nullptr, stream);
 }
 
 // =====================================================================================================================
@@ -368,8 +379,8 @@ __global__ __launch_bounds__(W, 2) void k_uvmlp_dgrad(const float *__restrict__ 
     const int r = lane & 31, h = lane >> 5;
     const int c4 = tid % C4N, rg = tid / C4N;
     const int D = plan.n_hidden;
-    const float *acts = saved + N * UVM_EPAD;
-    const unsigned long long *masks = (const unsigned long long *)(saved + N * (int64_t)(UVM_EPAD + D * W));
+    const float *acts = saved + N * plan.epad;
+    const unsigned long long *masks = (const unsigned long long *)(saved + N * (int64_t)(plan.epad + D * W));
 
     float wo[4][4], gwo[4][4];
 #pragma unroll
@@ -714,16 +725,18 @@ static void uvm_launch_wgrad(int G, const float *dz, const float *in, int64_t N,
 }
 
 extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, const float *raw, int64_t N, const void *packed,
-                                 int32_t D, int32_t W, int32_t L, int32_t output_ch, int32_t skip, const void *saved_v, void *ws,
+                                 int32_t D, int32_t W, int32_t dims, int32_t L, int32_t output_ch, int32_t skip, const void *saved_v, void *ws,
                                  float *const *gws, float *const *gbs, ctx_stream_t stream)
 {
     UvmPlan p; int64_t total = 0;
     CTX_REQUIRE(packed && saved_v && ws && gws && gbs && N > 0, "uvmlp_bwd: bad args");
     CTX_REQUIRE(grad_raw || grad_tex, "uvmlp_bwd: need grad_raw and / or grad_tex");
     CTX_REQUIRE(!grad_tex || raw, "uvmlp_bwd: grad_tex needs raw (the tanh argument)");
-    int input_ch = 2 * (1 + 2 * L);
+    CTX_REQUIRE(dims == 2 || dims == 3, "uvmlp_bwd: dims=%d (2: uv, 3: xyz)", dims);
+    int input_ch = dims * (1 + 2 * L);
     CTX_REQUIRE(uvm_build_plan(D, W, input_ch, output_ch, skip, p, total) == 0,
-                "uvmlp_bwd: unsupported D=%d W=%d L=%d output_ch=%d", D, W, L, output_ch);
+                "uvmlp_bwd: unsupported D=%d W=%d dims=%d L=%d output_ch=%d", D, W, dims, L, output_ch);
+    p.dims = dims;
     CTX_REQUIRE(skip >= 0 && skip + 1 < D, "uvmlp_bwd: skip=%d outside [0, D-2]", skip);
     for (int i = 0; i <= D; ++i) CTX_REQUIRE(gws[i] && gbs[i], "uvmlp_bwd: null gradient pointer for layer %d", i);
     hipStream_t s = (hipStream_t)stream;
@@ -762,7 +775,7 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
     chunk_e = (chunk_e + 47) / 48 * 48;
     int Ge = (int)cdiv64(N, chunk_e);
     const float *emb = saved;
-    const float *acts = saved + N * UVM_EPAD;
+    const float *acts = saved + N * p.epad;
     static const int wg8 = [] { const char *e = getenv("CTX_UVM_WG8"); return e ? atoi(e) : 0; }();
     for (int li = D - 1; li >= 0; --li) {
         const float *dzl = dz + (int64_t)li * N * W;
@@ -783,9 +796,15 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
         }
         if (has_emb) {
             float *bsl = has_hid ? nullptr : bslab;
-            if (W == 256) uvm_launch_wgrad<4, 1, 2, 2, 256, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
-            else if (W == 128) uvm_launch_wgrad<2, 1, 2, 2, 128, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
-            else uvm_launch_wgrad<1, 1, 2, 2, 64, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
+            if (p.epad == UVM_EPAD) {
+                if (W == 256) uvm_launch_wgrad<4, 1, 2, 2, 256, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
+                else if (W == 128) uvm_launch_wgrad<2, 1, 2, 2, 128, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
+                else uvm_launch_wgrad<1, 1, 2, 2, 64, UVM_EPAD, UVM_EPAD>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
+            } else {
+                if (W == 256) uvm_launch_wgrad<4, 1, 2, 2, 256, UVM_EPAD3, UVM_EPAD3>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
+                else if (W == 128) uvm_launch_wgrad<2, 1, 2, 2, 128, UVM_EPAD3, UVM_EPAD3>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
+                else uvm_launch_wgrad<1, 1, 2, 2, 64, UVM_EPAD3, UVM_EPAD3>(Ge, dzl, emb, N, chunk_e, slab, bsl, s);
+            }
             CTX_CHECK_LAUNCH("uvmlp_wgrad_emb");
             hipLaunchKernelGGL(k_uvm_reduce, dim3(cdiv(W * 64 / 4, 64)), dim3(256), 0, s, slab, Ge, (int64_t)W * 64, W, 64, input_ch, gws[li], kin, 0);
             if (!has_hid)

@@ -52,7 +52,7 @@ class _UvMlpFn(torch.autograd.Function):
         Lf = (net.input_ch // 2 - 1) // 2
         # the activation store (8.8 GB for the 1024^2 atlas) is kept by the module and handed out to one forward at a time;
         # allocating it per call makes the caching allocator split and re-malloc multi-GB blocks
-        nbytes = lib.ctx_uvmlp_saved_bytes(N, net.D, net.W)
+        nbytes = lib.ctx_uvmlp_saved_bytes(N, net.D, net.W, net.input_ch)
         saved = net._saved_pool if (net._saved_pool is not None and net._saved_pool.numel() == nbytes
                                     and net._saved_pool.device == dev) else None
         net._saved_pool = None
@@ -60,8 +60,8 @@ class _UvMlpFn(torch.autograd.Function):
             saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         raw = torch.empty(N, net.output_ch, device=dev)
         tex = torch.empty(net.output_ch, N, device=dev) if want_tex else None
-        L.check(lib.ctx_uvmlp_fwd_save(L.ptr(uv), L.ptr(emb), N, res, L.ptr(blob), net.D, net.W, Lf, net.output_ch,
-                                       net.skips[0], L.ptr(raw), L.ptr(tex), L.ptr(saved), L.stream()))
+        L.check(lib.ctx_uvmlp_fwd_save(L.ptr(uv), L.ptr(emb), N, res, L.ptr(blob), net.D, net.W, net.dims, net.multires,
+                                       net.output_ch, net.skips[0], L.ptr(raw), L.ptr(tex), L.ptr(saved), L.stream()))
         ctx.net, ctx.N, ctx.saved_acts, ctx.blob = net, N, saved, blob
         ctx.save_for_backward(raw)          # an output: kept through save_for_backward so the graph holds no reference cycle
         ctx.set_materialize_grads(False)
@@ -85,9 +85,8 @@ class _UvMlpFn(torch.autograd.Function):
         gbp = (C.c_void_p * len(gbs))(*[L.ptr(g).value for g in gbs])
         g_raw = None if g_raw is None else L.f32c(g_raw)
         g_tex = None if g_tex is None else L.f32c(g_tex)
-        Lf = (net.input_ch // 2 - 1) // 2
-        L.check(lib.ctx_uvmlp_bwd(L.ptr(g_raw), L.ptr(g_tex), L.ptr(raw), N, L.ptr(ctx.blob), net.D, net.W, Lf,
-                                  net.output_ch, net.skips[0], L.ptr(ctx.saved_acts), L.ptr(ws), gwp, gbp, L.stream()))
+        L.check(lib.ctx_uvmlp_bwd(L.ptr(g_raw), L.ptr(g_tex), L.ptr(raw), N, L.ptr(ctx.blob), net.D, net.W, net.dims,
+                                  net.multires, net.output_ch, net.skips[0], L.ptr(ctx.saved_acts), L.ptr(ws), gwp, gbp, L.stream()))
         net._saved_pool, ctx.saved_acts = ctx.saved_acts, None          # back to the module for the next forward
         grads = []
         for w, b in zip(gws, gbs):
@@ -106,10 +105,19 @@ class NeRF2D(nn.Module):
         for layer in self.pts_linears:
             nn.init.kaiming_normal_(layer.weight, mode='fan_in', nonlinearity='relu')
         nn.init.kaiming_normal_(self.output_linear.weight, mode='fan_in', nonlinearity='relu')
+        self.dims, self.multires = self._infer_dims(input_ch)
         self._packed = None
         self._packed_version = None
         self._saved_pool = None      # activation store of the training forward, reused across iterations
         self._bwd_ws = None          # backward scratch
+
+    @staticmethod
+    def _infer_dims(input_ch):
+        """input_ch = dims * (1 + 2L) with dims 2 (uv texture field) or 3 (xyz points of the ray path)."""
+        for d in (2, 3):
+            if input_ch % d == 0 and (input_ch // d - 1) % 2 == 0:
+                return d, (input_ch // d - 1) // 2
+        return 2, 0          # only the forward(embedded) seam is meaningful then; the kernel rejects it with a message
 
     # -- weight packing (cached; invalidated by in-place parameter updates via _version) --------------
     def _version(self):
@@ -125,7 +133,7 @@ class NeRF2D(nn.Module):
             n = lib.ctx_uvmlp_packed_bytes(self.D, self.W, self.input_ch, self.output_ch, self.skips[0])
             if n < 0:
                 raise L.CtxError(f"NeRF2D(D={self.D},W={self.W},input_ch={self.input_ch},output_ch={self.output_ch}) "
-                                 "is outside the fused kernel's envelope (W in 64/128/256, input_ch<=48, output_ch<=4)")
+                                 "is outside the fused kernel's envelope (W in 64/128/256, input_ch<=64, output_ch<=4)")
             blob = torch.empty(n, dtype=torch.uint8, device=dev)
             layers = list(self.pts_linears) + [self.output_linear]
             ws = [L.f32c(l.weight.detach()) for l in layers]
@@ -150,11 +158,10 @@ class NeRF2D(nn.Module):
         lib = L.load()
         blob = self.packed()
         dev = blob.device
-        Lf = (self.input_ch // 2 - 1) // 2
         raw = torch.empty(N, self.output_ch, device=dev)
         tex = torch.empty(self.output_ch, N, device=dev) if want_tex else None
-        L.check(lib.ctx_uvmlp_fwd(L.ptr(uv), L.ptr(emb), N, res, L.ptr(blob), self.D, self.W, Lf, self.output_ch,
-                                  self.skips[0], L.ptr(raw), L.ptr(tex), L.stream()))
+        L.check(lib.ctx_uvmlp_fwd_save(L.ptr(uv), L.ptr(emb), N, res, L.ptr(blob), self.D, self.W, self.dims, self.multires,
+                                       self.output_ch, self.skips[0], L.ptr(raw), L.ptr(tex), None, L.stream()))
         return raw, tex
 
     def forward(self, x):
@@ -162,6 +169,12 @@ class NeRF2D(nn.Module):
         e = L.f32c(x).reshape(-1, self.input_ch)
         raw, _ = self._run(None, e, e.shape[0], 0, False)
         return raw.reshape(*x.shape[:-1], self.output_ch)
+
+    def forward_pts(self, pts):
+        """Fused embed+MLP on raw points [..., dims] (dims 2: uv, 3: xyz) -> [..., output_ch]."""
+        x = L.f32c(pts).reshape(-1, self.dims)
+        raw, _ = self._run(x, None, x.shape[0], 0, False)
+        return raw.reshape(*pts.shape[:-1], self.output_ch)
 
     def forward_uv(self, uv):
         """Fused embed+MLP on raw uv [N,2]."""
@@ -241,3 +254,18 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
     L.check(lib.ctx_raymarch_composite_fwd(L.ptr(r, torch.float32, "raw"), L.ptr(z), L.ptr(d), R, S, int(white_bkgd), L.ptr(rgb),
                                            L.ptr(disp), L.ptr(acc), L.ptr(w), L.ptr(depth), L.stream()))
     return rgb, disp, acc, w, depth
+
+
+def render_rays(field, rays_o, rays_d, near, far, N_samples, white_bkgd=False, z_vals=None):
+    """The ray path north_star names (absent in the reference): nerf-pytorch's render_rays without perturbation /
+    hierarchical pass — z_vals = near*(1-t)+far*t for t = linspace(0,1,N_samples) (or the given z_vals, e.g. from
+    sample_pdf), pts = o + d*z, raw = field(pts) with field = NeRF2D(input_ch = 3*(1+2L), output_ch = 4) evaluated by the fused
+    embed+MLP kernel, then raw2outputs.  rays_o, rays_d: [R,3] -> (rgb [R,3], disp [R], acc [R], weights [R,S], depth [R])."""
+    ro, rd = L.f32c(rays_o).reshape(-1, 3), L.f32c(rays_d).reshape(-1, 3)
+    if z_vals is None:
+        t = torch.linspace(0., 1., steps=N_samples, device=ro.device)
+        z_vals = (near * (1. - t) + far * t).expand(ro.shape[0], N_samples)
+    z_vals = L.f32c(z_vals)
+    pts = ro[:, None, :] + rd[:, None, :] * z_vals[:, :, None]          # [R,S,3]
+    raw = field.forward_pts(pts)                                         # [R,S,4]
+    return raw2outputs(raw, z_vals, rd, white_bkgd=white_bkgd)

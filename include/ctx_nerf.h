@@ -120,11 +120,13 @@ int32_t ctx_uvmlp_fwd(const float *uv /*nullable*/, const float *emb /*nullable*
                       int32_t D, int32_t W, int32_t L, int32_t output_ch, int32_t skip,
                       float *raw, float *tex_chw /*nullable*/, ctx_stream_t stream);
 
-/* Training forward: as ctx_uvmlp_fwd, and keeps what the backward needs in `saved`
-   (ctx_uvmlp_saved_bytes(N,D,W) bytes: the padded embedding [N,48] and the post-ReLU activations [D,N,W], fp32). */
-int64_t ctx_uvmlp_saved_bytes(int64_t N, int32_t D, int32_t W);
+/* General / training forward.  dims = 2 (uv, as ctx_uvmlp_fwd) or 3 (xyz sample points of the ray path: the reference's
+   NeRF2D defaults, input_ch = 3*(1+2L) <= 64, output_ch = 4 = rgb + sigma); `uv` is then the [N,dims] point list.
+   saved (nullable: plain forward) keeps what the backward needs (ctx_uvmlp_saved_bytes(N,D,W,input_ch) bytes: the padded
+   embedding [N,48|64], the post-ReLU activations [D,N,W] fp32 and the ReLU pattern as bit masks). */
+int64_t ctx_uvmlp_saved_bytes(int64_t N, int32_t D, int32_t W, int32_t input_ch);
 int32_t ctx_uvmlp_fwd_save(const float *uv /*nullable*/, const float *emb /*nullable*/, int64_t N, int32_t res, const void *packed,
-                           int32_t D, int32_t W, int32_t L, int32_t output_ch, int32_t skip,
+                           int32_t D, int32_t W, int32_t dims, int32_t L, int32_t output_ch, int32_t skip,
                            float *raw, float *tex_chw /*nullable*/, void *saved /*nullable: plain forward*/, ctx_stream_t stream);
 /* Backward of NeRF2D.forward (autograd of src/run_nerf_helpers.py:106-135; the SDS loop src/training/trainer.py:644-907
    drives it with the atlas gradient).  Upstream gradient: grad_raw [N,output_ch] (d loss / d mlp_output) and / or
@@ -134,7 +136,7 @@ int32_t ctx_uvmlp_fwd_save(const float *uv /*nullable*/, const float *emb /*null
    ws: ctx_uvmlp_bwd_ws_bytes(N,D,W) bytes of scratch.  Deterministic (fixed-order partial sums). */
 int64_t ctx_uvmlp_bwd_ws_bytes(int64_t N, int32_t D, int32_t W);
 int32_t ctx_uvmlp_bwd(const float *grad_raw /*nullable*/, const float *grad_tex /*nullable*/, const float *raw /*nullable w/o grad_tex*/,
-                      int64_t N, const void *packed, int32_t D, int32_t W, int32_t L, int32_t output_ch, int32_t skip,
+                      int64_t N, const void *packed, int32_t D, int32_t W, int32_t dims, int32_t L, int32_t output_ch, int32_t skip,
                       const void *saved, void *ws, float *const *gws, float *const *gbs, ctx_stream_t stream);
 
 /* ---- ray path (north_star; dead/absent in the reference) ------------------------ */

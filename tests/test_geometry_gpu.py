@@ -300,18 +300,20 @@ def _field_bwd_abi(net, uv, c_raw, res=0, c_tex=None):
     dev = c_raw.device
     N, D, W = c_raw.shape[0], net.D, net.W
     blob = net.packed()
-    raw = torch.empty(N, 3, device=dev)
-    saved = torch.zeros(lib.ctx_uvmlp_saved_bytes(N, D, W) // 4, device=dev)
-    L.check(lib.ctx_uvmlp_fwd_save(L.ptr(uv), None, N, res, L.ptr(blob), D, W, 10, 3, 4, L.ptr(raw), None, L.ptr(saved), L.stream()))
+    raw = torch.empty(N, net.output_ch, device=dev)
+    saved = torch.zeros(lib.ctx_uvmlp_saved_bytes(N, D, W, net.input_ch) // 4, device=dev)
+    L.check(lib.ctx_uvmlp_fwd_save(L.ptr(uv), None, N, res, L.ptr(blob), D, W, net.dims, net.multires, net.output_ch, 4, L.ptr(raw), None,
+                                   L.ptr(saved), L.stream()))
     ws = torch.empty(lib.ctx_uvmlp_bwd_ws_bytes(N, D, W), dtype=torch.uint8, device=dev)
     layers = list(net.pts_linears) + [net.output_linear]
     gws = [torch.empty_like(l.weight) for l in layers]
     gbs = [torch.empty_like(l.bias) for l in layers]
     gwp = (C.c_void_p * (D + 1))(*[L.ptr(t).value for t in gws])
     gbp = (C.c_void_p * (D + 1))(*[L.ptr(t).value for t in gbs])
-    L.check(lib.ctx_uvmlp_bwd(L.ptr(c_raw), L.ptr(c_tex), L.ptr(raw), N, L.ptr(blob), D, W, 10, 3, 4, L.ptr(saved), L.ptr(ws), gwp, gbp,
-                              L.stream()))
-    return gws, gbs, saved[N * 48:N * 48 + D * N * W].reshape(D, N, W)     # (the ReLU bit masks follow)
+    L.check(lib.ctx_uvmlp_bwd(L.ptr(c_raw), L.ptr(c_tex), L.ptr(raw), N, L.ptr(blob), D, W, net.dims, net.multires, net.output_ch, 4,
+                              L.ptr(saved), L.ptr(ws), gwp, gbp, L.stream()))
+    ep = 48 if net.input_ch <= 48 else 64
+    return gws, gbs, saved[N * ep:N * ep + D * N * W].reshape(D, N, W)     # (the ReLU bit masks follow)
 
 
 @pytest.mark.parametrize("W,N", [(64, 1), (128, 517), (256, 4133), (256, 64 * 300), (256, 64 * 700 + 5)])
@@ -388,6 +390,70 @@ def test_texture_map_backward_and_fit(dev):
     with torch.no_grad():
         t2, _ = net.texture_map(res)                 # inference path sees the updated weights (packed blob re-made)
     assert abs(((t2 - target) ** 2).mean().item() - losses[-1]) < losses[0]
+
+
+def test_volume_render_3d_field(dev, golden):
+    """BASELINE configs[4] in small: get_rays -> stratified samples -> 3-D Fourier embed (63) -> NeRF2D(input_ch 63, output_ch 4)
+    -> raw2outputs, against the oracle (numpy embed / MLP in float64, C compositing).  Parity unpinned vs a reference run
+    (the reference has no ray-march body); the pieces are pinned separately (embed, NeRF2D, get_rays: golden)."""
+    from contexture_nerf_amd import run_nerf_helpers as rnh
+    H = W_ = 24
+    f = 12.0 / np.tan(np.pi / 6)
+    K = np.array([[f, 0, W_ / 2], [0, f, H / 2], [0, 0, 1]], np.float32)
+    c2w = torch.tensor(golden['rays_c2w'], device=dev)
+    ro, rd = rnh.get_rays(H, W_, K, c2w)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    torch.manual_seed(21)
+    field = rnh.NeRF2D(D=8, W=256, input_ch=63, output_ch=4, skips=[4]).to(dev)
+    assert (field.dims, field.multires) == (3, 10)
+    S = 40
+    with torch.no_grad():
+        rgb, disp, acc, wts, depth = rnh.render_rays(field, ro, rd, near=0.5, far=2.5, N_samples=S)
+        # the fused embedding == ctx_embed_fwd followed by the embedded-input seam
+        t = torch.linspace(0., 1., S, device=dev)
+        z = (0.5 * (1 - t) + 2.5 * t).expand(ro.shape[0], S).contiguous()
+        pts = ro[:, None, :] + rd[:, None, :] * z[:, :, None]
+        embed3 = rnh.Embedder(3, 10)
+        raw_seam = field(embed3.embed(pts.reshape(-1, 3)))
+        raw_fused = field.forward_pts(pts).reshape(-1, 4)
+    np.testing.assert_allclose(raw_fused.cpu().numpy(), raw_seam.cpu().numpy(), rtol=1e-4, atol=2e-4)
+    ws = [l.weight.detach().cpu().numpy() for l in field.pts_linears]
+    bs = [l.bias.detach().cpu().numpy() for l in field.pts_linears]
+    e = onerf.embed(pts.reshape(-1, 3).cpu().numpy())
+    assert e.shape[1] == 63
+    raw_o = onerf.nerf2d_forward(e, ws, bs, field.output_linear.weight.detach().cpu().numpy(),
+                                 field.output_linear.bias.detach().cpu().numpy(), dtype=np.float64)
+    # sin/cos arguments reach |x| * 2^9 ~ 1e3: the fp32 embedding differs from the float64 one by ~1e-4 there
+    np.testing.assert_allclose(raw_fused.cpu().numpy(), raw_o, rtol=2e-3, atol=2e-3)
+    o = og.raw2outputs(raw_fused.reshape(-1, S, 4).cpu().numpy(), z.cpu().numpy(), rd.cpu().numpy(), white_bkgd=False)
+    for a, b in zip((rgb, disp, acc, wts, depth), o):
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=2e-4, atol=2e-6)
+    assert rgb.shape == (H * W_, 3) and torch.isfinite(rgb).all()
+
+
+def test_field_3d_backward(dev):
+    """the 3-D field (padded embedding 64, 4 outputs) through the same backward, ragged N."""
+    from contexture_nerf_amd import run_nerf_helpers as rnh
+    torch.manual_seed(33)
+    net = rnh.NeRF2D(D=8, W=256, input_ch=63, output_ch=4, skips=[4]).to(dev)
+    N = 64 * 37 + 11
+    g = torch.Generator().manual_seed(4)
+    pts = torch.rand(N, 3, generator=g) * 2 - 1
+    c_raw = torch.randn(N, 4, generator=g)
+    hw, hb, acts = _field_bwd_abi(net, pts.to(dev), c_raw.to(dev))
+    acts = acts.cpu().numpy()
+    ws = [l.weight.detach().cpu().numpy() for l in net.pts_linears]
+    bs = [l.bias.detach().cpu().numpy() for l in net.pts_linears]
+    gws, gbs = onerf.nerf2d_backward(onerf.embed(pts.numpy()), ws, bs, net.output_linear.weight.detach().cpu().numpy(),
+                                     net.output_linear.bias.detach().cpu().numpy(), grad_raw=c_raw.numpy(),
+                                     masks=[acts[i] > 0 for i in range(8)])
+    for i in range(9):
+        _close(hw[i], gws[i], 1e-4, f'3-D field gw{i}')
+        _close(hb[i], gbs[i], 1e-4, f'3-D field gb{i}')
+    raw = net.forward_pts(pts.to(dev))
+    (raw * c_raw.to(dev)).sum().backward()
+    aw, ab = _field_grads(net)
+    assert all(torch.equal(a, b) for a, b in zip(hw, aw)) and all(torch.equal(a, b) for a, b in zip(hb, ab))
 
 
 def test_rays_and_composite(dev, golden):

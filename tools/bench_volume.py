@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] (ray path): get_rays(512,512) -> 128 stratified samples per ray -> fused 3-D embed + NeRF2D(63 -> 4) ->
+alpha compositing (nerf-pytorch raw2outputs).  FLOPs: 2*(63*256 + 6*256*256 + 319*256 + 256*4) per sample point."""
+import sys, os, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, importlib
+rnh = importlib.import_module('contexture_nerf_amd.run_nerf_helpers')
+
+HW = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+field = rnh.NeRF2D(D=8, W=256, input_ch=63, output_ch=4, skips=[4]).to(dev)
+f = (HW / 2) / np.tan(np.pi / 6)
+K = np.array([[f, 0, HW / 2], [0, f, HW / 2], [0, 0, 1]], np.float32)
+c2w = torch.tensor([[1, 0, 0, 0.0], [0, 1, 0, 0.0], [0, 0, 1, 1.5]], dtype=torch.float32, device=dev)
+flop_pt = 2 * (63 * 256 + 6 * 256 * 256 + 319 * 256 + 256 * 4)
+R = HW * HW
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+
+def step(timing=False):
+    with torch.no_grad():
+        ro, rd = rnh.get_rays(HW, HW, K, c2w)
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        t = torch.linspace(0., 1., S, device=dev)
+        z = (0.5 * (1 - t) + 2.5 * t).expand(R, S).contiguous()
+        pts = ro[:, None, :] + rd[:, None, :] * z[:, :, None]
+        if timing: ev[0].record()
+        raw = field.forward_pts(pts)
+        if timing: ev[1].record()
+        out = rnh.raw2outputs(raw, z, rd)
+        if timing: ev[2].record()
+    return out
+
+
+step(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(iters):
+    step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / iters
+step(True); torch.cuda.synchronize()
+t_field, t_comp = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+comp_bytes = R * S * 5 * 4 + R * 12 + R * 5 * 4 + R * S * 4
+print(json.dumps({"rays": R, "samples": S, "points": R * S, "image_ms": round(dt * 1e3, 2),
+                  "field_ms": round(t_field, 2), "field_tflops": round(flop_pt * R * S / t_field / 1e9, 1),
+                  "field_frac_of_f32_mfma_peak": round(flop_pt * R * S / t_field / 1e9 / 157.3, 3),
+                  "composite_ms": round(t_comp, 3), "composite_TBps": round(comp_bytes / t_comp / 1e9, 2),
+                  "composite_frac_of_8TBps": round(comp_bytes / t_comp / 1e9 / 8.0, 3)}))

@@ -19,4 +19,5 @@ timeout -k 10 120 python3 tools/bench_gemm.py 3 all > $OUT/r01_gemm_layers.txt 2
 timeout -k 10 300 python3 tools/bench_mesh.py 2>/dev/null | tail -1 > $OUT/r01_mesh_bench.json
 timeout -k 10 200 python3 tools/bench_concurrent.py 96 10 2>/dev/null | grep view > $OUT/r01_views_in_flight.txt
 timeout -k 10 200 python3 tools/bench_uvmlp.py 1024 5 2>/dev/null | tail -1 > $OUT/r01_uvmlp_bench.json
+timeout -k 10 200 python3 tools/bench_volume.py 512 128 3 2>/dev/null | tail -1 > $OUT/r01_volume_bench.json
 ls $OUT
