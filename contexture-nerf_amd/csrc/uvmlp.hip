@@ -156,16 +156,22 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
                                                  const float *__restrict__ packed, UvmPlan plan,
                                                  float *__restrict__ raw, float *__restrict__ tex, float *__restrict__ saved)
 {
-    constexpr int STRIDE = EP + W + 4;   // 308 / 324 for W=256: 4 x odd -> conflict-free ds_read_b128 rows
+    // 2-D field (EP = 48): embedding in columns [0,48), hidden vector in [48,48+W), 78.8 KB -> two workgroups per CU.
+    // 3-D field (EP = 64): that layout would be 82.9 KB (one workgroup per CU), so the hidden vector overlays the embedding
+    // ([0,W), 66.6 KB) and the skip layer re-creates the embedding in place after its hidden-part k-blocks.
+    constexpr bool RC = EP > UVM_EPAD;
+    constexpr int HOFF = RC ? 0 : EP;
+    constexpr int STRIDE = HOFF + W + 4;   // 308 / 260 for W=256: 4 x odd -> conflict-free ds_read_b128 rows
     static_assert((STRIDE / 4) % 2 == 1, "row stride must be 4 x odd");
+    static_assert(W >= EP || !RC, "the overlay needs W >= 64");
     extern __shared__ __attribute__((aligned(16))) float act[];   // [UVM_TM][STRIDE]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t n0 = (int64_t)blockIdx.x * UVM_TM;
 
-    // ---- Fourier embedding into columns [0,48) -------------------------------------------------
-    {
+    // ---- Fourier embedding into columns [0,EP) -------------------------------------------------
+    auto put_embedding = [&]() {
         int row = tid & 63;
         int64_t n = n0 + row;
         const int d = plan.dims;
@@ -192,7 +198,8 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
             }
             act[row * STRIDE + e] = val;
         }
-    }
+    };
+    put_embedding();
     __syncthreads();
     if (saved) {   // training: keep the (padded) embedding for the weight gradients of layer 0 and the skip layer
         for (int i = tid; i < UVM_TM * (EP / 4); i += W) {
@@ -212,34 +219,45 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
         const float4 *wp = (const float4 *)(packed + ly.w_off) + ((size_t)(wave * 2) * 64 + lane);
-        const int nkb = ly.kp / 8;
-        const float *arow0 = act + r * STRIDE + ly.col0 + 4 * h;
-        const float *arow1 = arow0 + 32 * STRIDE;
-        auto kstep = [&](int kb, const float4 &b0, const float4 &b1) {
-            float4 a0 = *(const float4 *)(arow0 + kb * 8);
-            float4 a1 = *(const float4 *)(arow1 + kb * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+        constexpr size_t KBS = (size_t)(W / 32) * 64;   // float4 per k-block
+        // k-blocks [kb0, kb1) of the layer's packed weights against LDS columns lc0 + 8 (kb - kb0) ...
+        auto run_k = [&](int kb0, int kb1, int lc0) {
+            const float *arow0 = act + r * STRIDE + lc0 + 4 * h - kb0 * 8;
+            const float *arow1 = arow0 + 32 * STRIDE;
+            auto kstep = [&](int kb, const float4 &b0, const float4 &b1) {
+                float4 a0 = *(const float4 *)(arow0 + kb * 8);
+                float4 a1 = *(const float4 *)(arow1 + kb * 8);
+                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+                const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+                }
+            };
+            const float4 *p0 = wp + (size_t)kb0 * KBS;
+            float4 wa0 = p0[0], wa1 = p0[64], wb0, wb1;
+            for (int kb = kb0; kb < kb1; kb += 2) {          // every k-block range here has an even length
+                const float4 *pb = wp + (size_t)uvm_opaque(kb + 1) * KBS;
+                wb0 = pb[0]; wb1 = pb[64];
+                __builtin_amdgcn_sched_barrier(0);           // keep the prefetch above the MFMAs it hides under
+                kstep(kb, wa0, wa1);
+                const float4 *pa = wp + (size_t)uvm_opaque(kb + 2 < kb1 ? kb + 2 : kb) * KBS;
+                wa0 = pa[0]; wa1 = pa[64];
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(kb + 1, wb0, wb1);
             }
         };
-        constexpr size_t KBS = (size_t)(W / 32) * 64;   // float4 per k-block
-        float4 wa0 = wp[0], wa1 = wp[64], wb0, wb1;
-        for (int kb = 0; kb < nkb; kb += 2) {            // every padded K is a multiple of 16
-            const float4 *pb = wp + (size_t)uvm_opaque(kb + 1) * KBS;
-            wb0 = pb[0]; wb1 = pb[64];
-            __builtin_amdgcn_sched_barrier(0);           // keep the prefetch above the MFMAs it hides under
-            kstep(kb, wa0, wa1);
-            const float4 *pa = wp + (size_t)uvm_opaque(kb + 2 < nkb ? kb + 2 : kb) * KBS;
-            wa0 = pa[0]; wa1 = pa[64];
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(kb + 1, wb0, wb1);
-        }
+        if (!RC) run_k(0, ly.kp / 8, ly.col0);
+        else if (ly.kp == EP + W) {                          // skip layer of the overlaid layout: hidden part, then embedding
+            run_k(EP / 8, (EP + W) / 8, 0);
+            __syncthreads();
+            put_embedding();
+            __syncthreads();
+            run_k(0, EP / 8, 0);
+        } else run_k(0, ly.kp / 8, 0);
         __syncthreads();   // everyone has finished reading this layer's input
         const float *bias = packed + ly.b_off;
         unsigned long long relu_bits = 0;   // bit (nb*2+mb)*16+q of this lane: its accumulator element is > 0
@@ -254,7 +272,7 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
                     int row = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                     float v = acc[mb][nb][q] + bv;
                     relu_bits |= (unsigned long long)(v > 0.f) << ((nb * 2 + mb) * 16 + q);
-                    act[row * STRIDE + EP + col] = v > 0.f ? v : 0.f;
+                    act[row * STRIDE + HOFF + col] = v > 0.f ? v : 0.f;
                 }
         }
         if (saved) {   // the ReLU pattern in the accumulator layout the backward chain's tiles have: [layer][tile][thread] u64
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
             float *dst = saved + N * EP + (int64_t)li * N * W;
             for (int i = tid; i < UVM_TM * (W / 4); i += W) {
                 int row = i / (W / 4), c4 = i % (W / 4);
-                if (n0 + row < N) *(float4 *)(dst + (n0 + row) * W + c4 * 4) = *(const float4 *)(act + row * STRIDE + EP + c4 * 4);
+                if (n0 + row < N) *(float4 *)(dst + (n0 + row) * W + c4 * 4) = *(const float4 *)(act + row * STRIDE + HOFF + c4 * 4);
             }
         }
     }
@@ -275,7 +293,7 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
     {
         constexpr int PARTS = W / 64;            // threads per texel
         int row = tid / PARTS, part = tid % PARTS;
-        const float *a = act + row * STRIDE + EP + part * 64;
+        const float *a = act + row * STRIDE + HOFF + part * 64;
         const float *ow = packed + plan.out_w_off + part * 64;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < 64; ++k) {
@@ -322,7 +340,7 @@ extern "C" int32_t ctx_uvmlp_fwd_save(const float *uv, const float *emb, int64_t
     p.dims = dims;
     hipStream_t s = (hipStream_t)stream;
     unsigned grid = (unsigned)cdiv64(N, UVM_TM);
-    size_t lds = (size_t)UVM_TM * (p.epad + W + 4) * 4;
+    size_t lds = (size_t)UVM_TM * ((p.epad == UVM_EPAD ? UVM_EPAD : 0) + W + 4) * 4;   // the 3-D layout overlays the embedding
     const float *pk = (const float *)packed;
 #define UVM_FWD(WW, EE)                                                                                                     \
     do {                                                                                                                    \
