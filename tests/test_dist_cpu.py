@@ -50,6 +50,14 @@ def _worker(rank, world, port, tmp):
         tot += contrib_all[[k for k in range(B) if k % world == rk]].sum(0)
     np.testing.assert_allclose(cov.numpy(), tot[3], rtol=0, atol=0)
     np.testing.assert_allclose(atlas.numpy(), tot[:3] / np.maximum(tot[3:], 1e-8), rtol=1e-6, atol=1e-6)
+    # ray path (configs[4]): contiguous row tiles, ragged H, gathered image == the unsharded one
+    from contexture_nerf_amd import volume_render as vr
+    Hh = 13
+    img = torch.arange(Hh * 5 * 3, dtype=torch.float32).reshape(Hh, 5, 3)
+    r0, r1 = vr.shard_rows(Hh, rank, world)
+    assert (r0, r1) == ((0, 7) if rank == 0 else (7, 13))
+    assert torch.equal(vr.gather_rows(img[r0:r1].clone(), Hh), img)
+    assert torch.equal(vr.gather_rows(img[r0:r1, :, 0].clone(), Hh), img[:, :, 0])
     torch.save(torch.tensor(1), os.path.join(tmp, f"ok{rank}"))
     dist.destroy_process_group()
 

@@ -44,7 +44,25 @@ dt = (time.perf_counter() - t0) / iters
 step(True); torch.cuda.synchronize()
 t_field, t_comp = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
 comp_bytes = R * S * 5 * 4 + R * 12 + R * 5 * 4 + R * S * 4
-print(json.dumps({"rays": R, "samples": S, "points": R * S, "image_ms": round(dt * 1e3, 2),
+out_extra = {}
+if os.environ.get("CTX_VOLUME_REFINE", "1") != "0":
+    # + the SD2-depth refine of configs[4]: 50 PLMS steps (51 UNet evaluations, CFG batch 2) at HW x HW, VAE decode
+    vr = importlib.import_module('contexture_nerf_amd.volume_render')
+    sdm = importlib.import_module('contexture_nerf_amd.stable_diffusion_depth')
+    sd = sdm.StableDiffusion(dev)
+    with torch.no_grad():
+        field.output_linear.bias[3] = 3.0
+    text_z = sd.get_text_embeds(["a photo of a human"])
+
+    def whole():
+        return vr.render_and_refine(field, sd, text_z, HW, HW, c2w, N_samples=S, num_inference_steps=50, image_size=HW)
+    whole(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    img, _ = whole()
+    torch.cuda.synchronize()
+    out_extra = {"render_plus_refine_ms": round((time.perf_counter() - t1) * 1e3, 1), "refine_steps": 50,
+                 "refined_finite": bool(torch.isfinite(img).all())}
+print(json.dumps({**out_extra, "rays": R, "samples": S, "points": R * S, "image_ms": round(dt * 1e3, 2),
                   "field_ms": round(t_field, 2), "field_tflops": round(flop_pt * R * S / t_field / 1e9, 1),
                   "field_frac_of_f32_mfma_peak": round(flop_pt * R * S / t_field / 1e9 / 157.3, 3),
                   "composite_ms": round(t_comp, 3), "composite_TBps": round(comp_bytes / t_comp / 1e9, 2),
