@@ -90,7 +90,7 @@ def test_trainer_view_weights_paint_and_atlas(dev, meshes):
                                background=torch.tensor([0.5, 0.5, 0.5], device=dev))
     assert set(out) == {'image', 'mask', 'background', 'foreground', 'depth', 'normals', 'render_cache', 'texture_map', 'mlp_output'}
     assert out['image'].shape == (2, 3, 160, 160) and out['texture_map'].shape == (1, 3, 128, 128)
-    assert float(out['image'].min()) >= 0 and float(out['image'].max()) <= 1
+    assert float(out['image'].detach().min()) >= 0 and float(out['image'].detach().max()) <= 1
     m = out['mask'][0, 0] > 0
     assert 0.1 < m.float().mean() < 0.9
     d = out['depth'][0, 0]

@@ -188,11 +188,14 @@ def test_tuned_plans_against_torch(dev):
         if conv:
             Cin = K // 9
             st, up = (2 if flags & 1 else 1), (1 if flags & 2 else 0)
-            # recover the input grid: M = 2 * Ho * Wo, square; Ho = (H << up - 1) // st + 1
-            Ho = int(round((M // 2) ** 0.5)); assert 2 * Ho * Ho == M
+            # recover the input grid: M = Bn * Ho * Wo, square, Bn = 2 (CFG pair) or 1; Ho = (H << up - 1) // st + 1
+            Ho = int(round((M // 2) ** 0.5)); Bn = 2
+            if 2 * Ho * Ho != M:
+                Ho = int(round(M ** 0.5)); Bn = 1
+            assert Bn * Ho * Ho == M
             H = Ho // 2 if up else (Ho * 2 if st == 2 else Ho)
-            x = torch.randn(2, H, H, Cin, generator=g, device=dev).half()
-            cb = (2, H, H, Cin, flags)
+            x = torch.randn(Bn, H, H, Cin, generator=g, device=dev).half()
+            cb = (Bn, H, H, Cin, flags)
         else:
             x = torch.randn(M, K, generator=g, device=dev).half()
             cb = (0, 0, 0, 0, 0)
