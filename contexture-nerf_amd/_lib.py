@@ -63,6 +63,9 @@ SIGNATURES = {
     "ctx_vae_bind": (_i32, [_vp, _vp, _vp, _i64]),
     "ctx_vae_set_param": (_i32, [_vp, _i32, _vp, _vp]),
     "ctx_vae_decode": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "ctx_vae_decoder_param_count": (_i32, [_vp]),
+    "ctx_vae_encode_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
+    "ctx_vae_encode": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ctx_vae_flops": (C.c_double, [_vp]),
     "ctx_gemm_f16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ctx_conv3x3_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
 
     auto retap = [&]() {                            // CONV: new 3x3 tap -> recompute the activation pointers
         int tap = k_issue / a.Cin, c0 = k_issue - tap * a.Cin;
-        int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        int dy = tap / 3 - 1 + a.poff, dx = tap % 3 - 1 + a.poff;
         int Hv = a.H << a.ups, Wv = a.W << a.ups;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
             const int h = kind == 0 ? 0 : 1;
             const int k0 = (kbeg + t) * 64;
             const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const int dy = tap / 3 - 1 + a.poff, dx = tap - (tap / 3) * 3 - 1 + a.poff;
             const int Hv = a.H << a.ups, Wv = a.W << a.ups;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {

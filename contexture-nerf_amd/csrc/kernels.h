@@ -16,6 +16,8 @@ struct GemmArgs {
     int epi;               // 0 plain, 1 GEGLU (out has N/2 columns)
     // conv
     int H, W, Cin, Ho, Wo, stride, ups;
+    int poff;              // conv input-coordinate offset: 0 = symmetric padding 1; 1 = no top/left padding (diffusers' VAE
+                           // Downsample2D: F.pad(x, (0,1,0,1)) then a stride-2 conv with padding 0)
     int ntm, ntn;
     int splitk;            // >1: grid.y = splitk, fp32 partials [splitk][M][N] go to `part`
     float *part;

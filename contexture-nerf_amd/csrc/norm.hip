@@ -277,7 +277,8 @@ extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const voi
     size_t total = (size_t)HW * c8n;
     // fat blocks (the per-block fold of the split partials is amortised), at least one batch each
     int nb = (int)((total + 256 * GN_AU - 1) / (256 * GN_AU));
-    const int cap = B >= 2 ? 128 : 256;                       // ~one block per CU: the per-block fold of the partials is not free
+    static const int cap_env = [] { const char *e = getenv("CTX_GN_APPLY_CAP"); return e ? atoi(e) : 0; }();
+    const int cap = cap_env > 0 ? cap_env : (B >= 2 ? 128 : 256);   // ~one block per CU: the per-block fold of the partials is not free
     if (nb > cap) nb = cap;
     hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, (const f16 *)x, part, (const f16 *)gamma,
                        (const f16 *)beta, HW, C, groups, NS, eps, silu, (f16 *)y);

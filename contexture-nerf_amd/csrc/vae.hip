@@ -1,5 +1,7 @@
-// VAE decoder engine: diffusers `AutoencoderKL.decode` (post_quant_conv + Decoder) as used by
-// StableDiffusion.decode_latents (src/stable_diffusion_depth.py:976-990): latents [B,4,h,w] -> image [B,3,8h,8w].
+// VAE engine: diffusers `AutoencoderKL.decode` (post_quant_conv + Decoder) as used by
+// StableDiffusion.decode_latents (src/stable_diffusion_depth.py:976-990): latents [B,4,h,w] -> image [B,3,8h,8w], and
+// `AutoencoderKL.encode` (Encoder + quant_conv) behind StableDiffusion.encode_imgs (:971-975): image [B,3,8h,8w] ->
+// moments [B,8,h,w] (mean | logvar of the latent distribution; sampling stays with the caller's RNG).
 // Reuses the UNet's fp16 MFMA conv / GEMM and GroupNorm kernels; the single-head (dim 512) mid-block attention is run
 // as two GEMMs around a row softmax (scores are materialised: it is one call per painted view, not per denoise step).
 // Parameter names follow the diffusers AutoencoderKL state_dict ("decoder.up_blocks.2.resnets.0.conv1.weight", ...).
@@ -10,19 +12,28 @@
 
 struct VParam { std::string name; int ndim; int64_t shape[4]; int kind; size_t dst; int a, b; };   // kind: 0 copy, 1 conv3, 2 convin
 struct VRes { int cin, cout; size_t n1g, n1b, c1w, c1b, n2g, n2b, c2w, c2b, scw, scb; };
+struct VAttn { size_t ng, nb, qkv, qkvb, ow, ob; };
 
 struct ctx_vae {
     ctx_vae_config_t cfg;
     std::vector<VParam> params;
     size_t wtop = 0;
-    size_t pqw, pqb, ciw, cib, ang, anb, aqkv, aqkvb, aow, aob, cng, cnb, cow, cob;
+    size_t pqw, pqb, ciw, cib, cng, cnb, cow, cob;
+    VAttn att;
     VRes mid[2];
+    // encoder
+    size_t e_ciw, e_cib, e_cng, e_cnb, e_cow, e_cob, qw, qb;
+    VAttn e_att;
+    VRes e_mid[2];
+    std::vector<std::vector<VRes>> down;
+    std::vector<size_t> dnw, dnb;
     std::vector<std::vector<VRes>> up;
     std::vector<size_t> upw, upb;
     std::vector<int> upc;
     f16 *W = nullptr; char *ws = nullptr; size_t ws_cap = 0, top = 0, peak = 0;
     bool dry = false; hipStream_t s = nullptr; int rc = 0;
     double flops = 0;
+    int n_dec_params = 0;
 
     size_t walloc(size_t n) { size_t o = wtop; wtop += (n + 127) / 128 * 128; return o; }
     size_t add(const std::string &name, std::vector<int64_t> shp, int kind, size_t dst, int a = 0, int b = 0)
@@ -59,6 +70,19 @@ static void vadd_res(ctx_vae *v, const std::string &p, int cin, int cout, VRes &
     } else r.scw = r.scb = 0;
 }
 
+static void vadd_attn(ctx_vae *v, const std::string &ap, int top, VAttn &a)
+{
+    a.ng = v->vec(ap + ".group_norm.weight", top); a.nb = v->vec(ap + ".group_norm.bias", top);
+    a.qkv = v->walloc((size_t)3 * top * top); a.qkvb = v->walloc((size_t)3 * top);
+    const char *qkv[3] = {"to_q", "to_k", "to_v"};
+    for (int k = 0; k < 3; ++k) {
+        v->add(ap + "." + qkv[k] + ".weight", {top, top}, 0, a.qkv + (size_t)k * top * top);
+        v->add(ap + "." + qkv[k] + ".bias", {top}, 0, a.qkvb + (size_t)k * top);
+    }
+    a.ow = v->add(ap + ".to_out.0.weight", {top, top}, 0, v->walloc((size_t)top * top));
+    a.ob = v->vec(ap + ".to_out.0.bias", top);
+}
+
 extern "C" ctx_vae_t *ctx_vae_create(const ctx_vae_config_t *cfg)
 {
     if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->latent_channels > 8 || cfg->out_channels > 4 || cfg->groups > 64 ||
@@ -76,16 +100,7 @@ extern "C" ctx_vae_t *ctx_vae_create(const ctx_vae_config_t *cfg)
     v->ciw = v->add("decoder.conv_in.weight", {top, L, 3, 3}, 2, v->walloc((size_t)top * 72), top, L);
     v->cib = v->vec("decoder.conv_in.bias", top);
     vadd_res(v, "decoder.mid_block.resnets.0", top, top, v->mid[0]);
-    const std::string ap = "decoder.mid_block.attentions.0";
-    v->ang = v->vec(ap + ".group_norm.weight", top); v->anb = v->vec(ap + ".group_norm.bias", top);
-    v->aqkv = v->walloc((size_t)3 * top * top); v->aqkvb = v->walloc((size_t)3 * top);
-    const char *qkv[3] = {"to_q", "to_k", "to_v"};
-    for (int k = 0; k < 3; ++k) {
-        v->add(ap + "." + qkv[k] + ".weight", {top, top}, 0, v->aqkv + (size_t)k * top * top);
-        v->add(ap + "." + qkv[k] + ".bias", {top}, 0, v->aqkvb + (size_t)k * top);
-    }
-    v->aow = v->add(ap + ".to_out.0.weight", {top, top}, 0, v->walloc((size_t)top * top));
-    v->aob = v->vec(ap + ".to_out.0.bias", top);
+    vadd_attn(v, "decoder.mid_block.attentions.0", top, v->att);
     vadd_res(v, "decoder.mid_block.resnets.1", top, top, v->mid[1]);
     v->up.resize(n); v->upw.assign(n, 0); v->upb.assign(n, 0); v->upc.assign(n, 0);
     int out = top;
@@ -103,11 +118,38 @@ extern "C" ctx_vae_t *ctx_vae_create(const ctx_vae_config_t *cfg)
     v->cng = v->vec("decoder.conv_norm_out.weight", ch[0]); v->cnb = v->vec("decoder.conv_norm_out.bias", ch[0]);
     v->cow = v->add("decoder.conv_out.weight", {cfg->out_channels, ch[0], 3, 3}, 1, v->walloc((size_t)cfg->out_channels * ch[0] * 9), cfg->out_channels, ch[0]);
     v->cob = v->vec("decoder.conv_out.bias", cfg->out_channels);
+    // ---- encoder (diffusers Encoder: conv_in, DownEncoderBlock2D x n, UNetMidBlock2D, GroupNorm-SiLU-conv_out) + quant_conv.
+    // Registered after the decoder so a decoder-only checkpoint still fills a prefix of the table.
+    v->n_dec_params = (int)v->params.size();
+    v->e_ciw = v->add("encoder.conv_in.weight", {ch[0], cfg->out_channels, 3, 3}, 2, v->walloc((size_t)ch[0] * 72), ch[0], cfg->out_channels);
+    v->e_cib = v->vec("encoder.conv_in.bias", ch[0]);
+    v->down.resize(n); v->dnw.assign(n, 0); v->dnb.assign(n, 0);
+    int cur = ch[0];
+    for (int i = 0; i < n; ++i) {
+        std::string p = "encoder.down_blocks." + std::to_string(i);
+        v->down[i].resize(cfg->layers_per_block);
+        for (int j = 0; j < cfg->layers_per_block; ++j) { vadd_res(v, p + ".resnets." + std::to_string(j), j == 0 ? cur : ch[i], ch[i], v->down[i][j]); }
+        cur = ch[i];
+        if (i != n - 1) {
+            v->dnw[i] = v->add(p + ".downsamplers.0.conv.weight", {cur, cur, 3, 3}, 1, v->walloc((size_t)cur * cur * 9), cur, cur);
+            v->dnb[i] = v->vec(p + ".downsamplers.0.conv.bias", cur);
+        }
+    }
+    vadd_res(v, "encoder.mid_block.resnets.0", top, top, v->e_mid[0]);
+    vadd_attn(v, "encoder.mid_block.attentions.0", top, v->e_att);
+    vadd_res(v, "encoder.mid_block.resnets.1", top, top, v->e_mid[1]);
+    v->e_cng = v->vec("encoder.conv_norm_out.weight", top); v->e_cnb = v->vec("encoder.conv_norm_out.bias", top);
+    v->e_cow = v->add("encoder.conv_out.weight", {2 * L, top, 3, 3}, 1, v->walloc((size_t)2 * L * top * 9), 2 * L, top);
+    v->e_cob = v->vec("encoder.conv_out.bias", 2 * L);
+    v->qw = v->add("quant_conv.weight", {2 * L, 2 * L, 1, 1}, 0, v->walloc((size_t)4 * L * L));
+    v->qb = v->vec("quant_conv.bias", 2 * L);
     return v;
 }
 
 extern "C" void ctx_vae_destroy(ctx_vae_t *v) { delete v; }
 extern "C" int32_t ctx_vae_param_count(const ctx_vae_t *v) { return v ? (int32_t)v->params.size() : 0; }
+/* the first ctx_vae_decoder_param_count entries are post_quant_conv + decoder, the rest encoder + quant_conv */
+extern "C" int32_t ctx_vae_decoder_param_count(const ctx_vae_t *v) { return v ? v->n_dec_params : 0; }
 extern "C" const char *ctx_vae_param_name(const ctx_vae_t *v, int32_t i) { return (v && i >= 0 && i < (int)v->params.size()) ? v->params[i].name.c_str() : ""; }
 extern "C" int32_t ctx_vae_param_shape(const ctx_vae_t *v, int32_t i, int64_t shape4[4])
 {
@@ -215,13 +257,14 @@ static void vgemm(ctx_vae *v, const f16 *X, const f16 *Wt, const f16 *bias, cons
     VRUN(ctx_gemm_dispatch(a, false, v->s));
     v->top = mark;
 }
-static void vconv(ctx_vae *v, const f16 *x, size_t w, size_t bias, const f16 *res, int B, int H, int W, int Cin, int Cout, int ups, f16 *out)
+static void vconv(ctx_vae *v, const f16 *x, size_t w, size_t bias, const f16 *res, int B, int H, int W, int Cin, int Cout, int ups, f16 *out,
+                  int down = 0)
 {
     GemmArgs a = {};
-    a.Ho = H << ups; a.Wo = W << ups;
+    a.Ho = down ? H / 2 : H << ups; a.Wo = down ? W / 2 : W << ups;
     a.X = x; a.Wt = v->W + w; a.bias = v->W + bias; a.residual = res; a.out = out;
     a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Ho * a.Wo; a.ldrb = Cout;
-    a.H = H; a.W = W; a.Cin = Cin; a.stride = 1; a.ups = ups;
+    a.H = H; a.W = W; a.Cin = Cin; a.stride = down ? 2 : 1; a.ups = ups; a.poff = down ? 1 : 0;
     v->flops += 2.0 * a.M * a.N * a.K;
     size_t mark = v->top;
     ctx_gemm_plan(a, true);
@@ -253,28 +296,17 @@ static void vres(ctx_vae *v, const VRes &r, const f16 *x, int B, int H, int W, f
     v->top = mark;
 }
 
-static int vae_run(ctx_vae *v, const float *z, int B, int H, int W, float *img)
+// single-head attention of the mid block, dim = top: q,k,v GEMM -> per-batch scores GEMM -> softmax -> P.V GEMM -> out proj
+// (+residual o); the result lands in x.
+static int vattn(ctx_vae *v, const VAttn &at, const f16 *o, f16 *x, int B, int h, int w, int top, void *stats)
 {
-    const ctx_vae_config_t &c = v->cfg;
-    const int n = c.n_levels, top = c.block_out_channels[n - 1], L = c.latent_channels;
-    v->top = 0; v->peak = 0; v->rc = 0; v->flops = 0;
-    void *stats = v->alloc((size_t)ctx_groupnorm_ws_bytes(B, c.groups));
-    float *zq = (float *)v->alloc((size_t)B * L * H * W * 4);
-    if (!v->dry) hipLaunchKernelGGL(k_pointwise_small, dim3((unsigned)cdiv64((int64_t)B * H * W, 256)), dim3(256), 0, v->s, z, v->W + v->pqw,
-                                    v->W + v->pqb, B, L, (int64_t)H * W, zq);
-    int h = H, w = W;
-    f16 *x = v->allocH((size_t)B * h * w * top);
-    VRUN(ctx_conv_in_f16(zq, v->W + v->ciw, v->W + v->cib, B, L, h, w, top, x, v->s));
-    f16 *o = v->allocH((size_t)B * h * w * top);
-    vres(v, v->mid[0], x, B, h, w, o, stats);
-    {   // single-head attention, dim = top: q,k,v GEMM -> per-batch scores GEMM -> softmax -> P.V GEMM -> out proj (+residual)
         const int S = h * w, M = B * S;
         if (S % 64) { ctx_set_error("vae: latent h*w must be a multiple of 64 (got %d)", S); return CTX_E_ARG; }
         size_t mark = v->top;
         f16 *g = v->allocH((size_t)M * top);
-        vgn(v, o, v->ang, v->anb, B, S, top, 0, g, stats);
+        vgn(v, o, at.ng, at.nb, B, S, top, 0, g, stats);
         f16 *qkv = v->allocH((size_t)M * 3 * top);
-        vgemm(v, g, v->W + v->aqkv, v->W + v->aqkvb, nullptr, M, 3 * top, top, qkv);
+        vgemm(v, g, v->W + at.qkv, v->W + at.qkvb, nullptr, M, 3 * top, top, qkv);
         f16 *att = v->allocH((size_t)M * top);
         f16 *sc = v->allocH((size_t)S * S), *pr = v->allocH((size_t)S * S), *vt = v->allocH((size_t)top * S);
         f16 *qb = v->allocH((size_t)S * top), *kb = v->allocH((size_t)S * top);
@@ -291,11 +323,28 @@ static int vae_run(ctx_vae *v, const float *z, int B, int H, int W, float *img)
             vgemm(v, pr, vt, nullptr, nullptr, S, top, S, att ? att + (size_t)b * S * top : nullptr);
         }
         f16 *o2 = v->allocH((size_t)M * top);
-        vgemm(v, att, v->W + v->aow, v->W + v->aob, o, M, top, top, o2);
-        // o2 lives above the mark: copy down into x (free since conv_in's output is dead)
+        vgemm(v, att, v->W + at.ow, v->W + at.ob, o, M, top, top, o2);
+        // o2 lives above the mark: copy down into x (free since its previous content is dead)
         if (!v->dry) (void)hipMemcpyAsync(x, o2, (size_t)M * top * 2, hipMemcpyDeviceToDevice, v->s);
         v->top = mark;
-    }
+        return 0;
+}
+
+static int vae_run(ctx_vae *v, const float *z, int B, int H, int W, float *img)
+{
+    const ctx_vae_config_t &c = v->cfg;
+    const int n = c.n_levels, top = c.block_out_channels[n - 1], L = c.latent_channels;
+    v->top = 0; v->peak = 0; v->rc = 0; v->flops = 0;
+    void *stats = v->alloc((size_t)ctx_groupnorm_ws_bytes(B, c.groups));
+    float *zq = (float *)v->alloc((size_t)B * L * H * W * 4);
+    if (!v->dry) hipLaunchKernelGGL(k_pointwise_small, dim3((unsigned)cdiv64((int64_t)B * H * W, 256)), dim3(256), 0, v->s, z, v->W + v->pqw,
+                                    v->W + v->pqb, B, L, (int64_t)H * W, zq);
+    int h = H, w = W;
+    f16 *x = v->allocH((size_t)B * h * w * top);
+    VRUN(ctx_conv_in_f16(zq, v->W + v->ciw, v->W + v->cib, B, L, h, w, top, x, v->s));
+    f16 *o = v->allocH((size_t)B * h * w * top);
+    vres(v, v->mid[0], x, B, h, w, o, stats);
+    { int r = vattn(v, v->att, o, x, B, h, w, top, stats); if (r) return r; }
     vres(v, v->mid[1], x, B, h, w, o, stats);
     f16 *cur = o;
     int cc = top;
@@ -338,6 +387,88 @@ extern "C" int32_t ctx_vae_decode(ctx_vae_t *v, const float *latents, int32_t B,
     CTX_REQUIRE(B >= 1 && H >= 1 && W >= 1 && (H * W) % 64 == 0, "vae_decode: need h*w %% 64 == 0 (B=%d H=%d W=%d)", B, H, W);
     v->s = (hipStream_t)stream; v->dry = false;
     return vae_run(v, latents, B, H, W, image);
+}
+
+// quant_conv (1x1 over the 2L moment channels) on the encoder's f16 NHWC output -> f32 NCHW moments
+__global__ __launch_bounds__(256) void k_quant_moments(const f16 *__restrict__ x, const f16 *__restrict__ w, const f16 *__restrict__ b,
+                                                       int B, int C, int64_t HW, float *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * HW; i += (int64_t)gridDim.x * 256) {
+        int bb = (int)(i / HW); int64_t p = i % HW;
+        float in[16];
+        for (int c = 0; c < C; ++c) in[c] = (float)x[i * C + c];
+        for (int o = 0; o < C; ++o) {
+            float acc = (float)b[o];
+            for (int c = 0; c < C; ++c) acc += in[c] * (float)w[o * C + c];
+            y[((int64_t)bb * C + o) * HW + p] = acc;
+        }
+    }
+}
+
+// image f32 NCHW [B,3,H,W] (H, W multiples of 2^(n-1)) -> moments f32 NCHW [B,2L,H>>(n-1),W>>(n-1)]
+static int vae_encode_run(ctx_vae *v, const float *img, int B, int H, int W, float *moments)
+{
+    const ctx_vae_config_t &c = v->cfg;
+    const int n = c.n_levels, top = c.block_out_channels[n - 1], L2 = 2 * c.latent_channels;
+    v->top = 0; v->peak = 0; v->rc = 0; v->flops = 0;
+    void *stats = v->alloc((size_t)ctx_groupnorm_ws_bytes(B, c.groups));
+    int h = H, w = W, cc = c.block_out_channels[0];
+    f16 *cur = v->allocH((size_t)B * h * w * cc);
+    VRUN(ctx_conv_in_f16(img, v->W + v->e_ciw, v->W + v->e_cib, B, c.out_channels, h, w, cc, cur, v->s));
+    for (int i = 0; i < n; ++i) {
+        for (size_t j = 0; j < v->down[i].size(); ++j) {
+            int cout = v->down[i][j].cout;
+            f16 *nx = v->allocH((size_t)B * h * w * cout);
+            vres(v, v->down[i][j], cur, B, h, w, nx, stats);
+            cur = nx; cc = cout;
+        }
+        if (i != n - 1) {
+            f16 *nx = v->allocH((size_t)B * (h / 2) * (w / 2) * cc);
+            vconv(v, cur, v->dnw[i], v->dnb[i], nullptr, B, h, w, cc, cc, 0, nx, 1);
+            cur = nx; h /= 2; w /= 2;
+        }
+    }
+    f16 *o = v->allocH((size_t)B * h * w * top), *x = v->allocH((size_t)B * h * w * top);
+    vres(v, v->e_mid[0], cur, B, h, w, o, stats);
+    { int r = vattn(v, v->e_att, o, x, B, h, w, top, stats); if (r) return r; }
+    vres(v, v->e_mid[1], x, B, h, w, o, stats);
+    f16 *y = v->allocH((size_t)B * h * w * top);
+    vgn(v, o, v->e_cng, v->e_cnb, B, h * w, top, 1, y, stats);
+    f16 *m16 = v->allocH((size_t)B * h * w * L2);
+    vconv(v, y, v->e_cow, v->e_cob, nullptr, B, h, w, top, L2, 0, m16);
+    if (!v->dry && v->rc == 0)
+        hipLaunchKernelGGL(k_quant_moments, dim3((unsigned)cdiv64((int64_t)B * h * w, 256)), dim3(256), 0, v->s, m16, v->W + v->qw, v->W + v->qb, B,
+                           L2, (int64_t)h * w, moments);
+    if (!v->dry && v->rc == 0) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ctx_set_error("vae_encode: launch failed: %s", hipGetErrorString(e)); return CTX_E_LAUNCH; }
+    }
+    return v->rc;
+}
+
+static bool vae_encode_dims_ok(const ctx_vae *v, int B, int H, int W)
+{
+    const int f = 1 << (v->cfg.n_levels - 1);
+    return B >= 1 && H >= f && W >= f && H % f == 0 && W % f == 0 && ((H / f) * (W / f)) % 64 == 0 && v->cfg.latent_channels * 2 % 8 == 0;
+}
+
+extern "C" int64_t ctx_vae_encode_workspace_bytes(const ctx_vae_t *cv, int32_t B, int32_t H, int32_t W)
+{
+    ctx_vae *v = const_cast<ctx_vae *>(cv);
+    if (!v || !vae_encode_dims_ok(v, B, H, W)) return -1;
+    v->dry = true;
+    vae_encode_run(v, nullptr, B, H, W, nullptr);
+    v->dry = false;
+    return (int64_t)v->peak + 4096;
+}
+
+extern "C" int32_t ctx_vae_encode(ctx_vae_t *v, const float *image, int32_t B, int32_t H, int32_t W, float *moments, ctx_stream_t stream)
+{
+    CTX_REQUIRE(v && image && moments && v->W && v->ws, "vae_encode: null pointer / not bound");
+    CTX_REQUIRE(vae_encode_dims_ok(v, B, H, W), "vae_encode: need H, W multiples of %d with (H/%d)*(W/%d) %% 64 == 0 and 2*latent_channels %% 8 == 0 (B=%d H=%d W=%d)",
+                1 << (v->cfg.n_levels - 1), 1 << (v->cfg.n_levels - 1), 1 << (v->cfg.n_levels - 1), B, H, W);
+    v->s = (hipStream_t)stream; v->dry = false;
+    return vae_encode_run(v, image, B, H, W, moments);
 }
 
 extern "C" double ctx_vae_flops(const ctx_vae_t *v) { return v ? v->flops : 0.0; }

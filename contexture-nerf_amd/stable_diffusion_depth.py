@@ -57,8 +57,6 @@ class StableDiffusion:
         return self.scheduler.timesteps[t_start:], num_inference_steps - t_start
 
     def encode_imgs(self, imgs):
-        if not hasattr(self.vae, 'encode'):
-            raise L.CtxError("encode_imgs: the VAE encoder is not built (the reference's live path discards its result)")
         imgs = 2 * imgs - 1
         return self.vae.encode(imgs).latent_dist.sample() * 0.18215
 

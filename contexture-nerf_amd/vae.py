@@ -1,7 +1,7 @@
-"""AutoencoderKL (decoder): the `self.vae.decode(latents).sample` seam of src/stable_diffusion_depth.py:976-990
-(diffusers 0.27.2 class) on the HIP VAE engine.  Parameter names are diffusers' state_dict keys; offline the weights
-are seeded random-init.  The encoder (`encode_imgs`) is not built: the reference's live paint path discards the encoded
-render, so only decode sits on the hot path."""
+"""AutoencoderKL: the `self.vae.decode(latents).sample` and `self.vae.encode(imgs).latent_dist.sample()` seams of
+src/stable_diffusion_depth.py:971-990 (diffusers 0.27.2 class) on the HIP VAE engine.  Parameter names are diffusers'
+state_dict keys; offline the weights are seeded random-init.  Only decode sits on the paint path (the reference's live path
+discards the encoded render); encode is the forward half of SURVEY §8f n2."""
 import ctypes as C
 import math
 import types
@@ -36,6 +36,8 @@ class AutoencoderKL:
             self._names.append(self._lib.ctx_vae_param_name(self._h, i).decode())
             self._shapes.append(tuple(int(shp[k]) for k in range(nd)))
         self._index = {n: i for i, n in enumerate(self._names)}
+        self._n_dec = self._lib.ctx_vae_decoder_param_count(self._h)
+        self._has_encoder = True
         self._ws_key = None
         if self.device.type == 'cuda':
             self._weights = torch.empty(self._lib.ctx_vae_weight_bytes(self._h), dtype=torch.uint8, device=self.device)
@@ -66,8 +68,14 @@ class AutoencoderKL:
         return t
 
     def load_state_dict(self, sd, strict=True):
-        """Accepts a full AutoencoderKL state_dict; encoder / quant_conv keys are ignored (decoder-only engine)."""
+        """Accepts a full AutoencoderKL state_dict, or a decoder-only one (post_quant_conv + decoder.*): `encode` is then off."""
         missing = [n for n in self._names if n not in sd]
+        enc = set(self._names[self._n_dec:])
+        if missing and all(m in enc for m in missing) and len(missing) == len(enc):
+            self._has_encoder = False                       # decoder-only checkpoint
+            missing = []
+        elif not missing:
+            self._has_encoder = True
         if strict and missing:
             raise L.CtxError(f"load_state_dict: missing {missing[:5]} ({len(missing)})")
         keep = [self._set(i, sd[n]) for n, i in self._index.items() if n in sd]
@@ -105,5 +113,45 @@ class AutoencoderKL:
         L.check(self._lib.ctx_vae_decode(self._h, L.ptr(x, torch.float32, "latents"), B, H, W, L.ptr(out), L.stream()))
         return types.SimpleNamespace(sample=out)
 
+    def encode(self, x):
+        """x [B,3,H,W] in [-1,1] -> namespace(latent_dist=DiagonalGaussianDistribution-like with .sample() / .mode() / .mean / .logvar)."""
+        if not self._has_encoder:
+            raise L.CtxError("vae.encode: a decoder-only state_dict was loaded (no encoder.* / quant_conv.* parameters)")
+        x = L.f32c(x, self.device)
+        B, Cc, H, W = x.shape
+        if Cc != self.config['out_channels']:
+            raise L.CtxError(f"vae.encode: expected {self.config['out_channels']} image channels, got {Cc}")
+        need = self._lib.ctx_vae_encode_workspace_bytes(self._h, B, H, W)
+        if need < 0:
+            f = 2 ** (len(self.config['block_out_channels']) - 1)
+            raise L.CtxError(f"vae.encode: H, W must be multiples of {f} with (H/{f})*(W/{f}) a multiple of 64 (got {H}x{W})")
+        if self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._bind()
+        self._ws_key = None
+        f = 2 ** (len(self.config['block_out_channels']) - 1)
+        Lc = self.config['latent_channels']
+        mom = torch.empty(B, 2 * Lc, H // f, W // f, device=self.device)
+        L.check(self._lib.ctx_vae_encode(self._h, L.ptr(x, torch.float32, "image"), B, H, W, L.ptr(mom), L.stream()))
+        return types.SimpleNamespace(latent_dist=DiagonalGaussianDistribution(mom))
+
     def flops(self):
         return self._lib.ctx_vae_flops(self._h)
+
+
+class DiagonalGaussianDistribution:
+    """diffusers.models.autoencoders.vae.DiagonalGaussianDistribution (0.27.2) over moments [B,2L,h,w]."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator=None):
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.parameters.device, dtype=self.parameters.dtype)
+        return self.mean + self.std * noise
+
+    def mode(self):
+        return self.mean

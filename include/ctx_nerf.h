@@ -203,7 +203,15 @@ int32_t ctx_vae_bind(ctx_vae_t *v, void *weights, void *workspace, int64_t works
 int32_t ctx_vae_set_param(ctx_vae_t *v, int32_t i, const float *src, ctx_stream_t stream);
 /* latents [B,L,H,W] f32 (already divided by the 0.18215 scaling factor) -> image [B,3,8H,8W] f32 */
 int32_t ctx_vae_decode(ctx_vae_t *v, const float *latents, int32_t B, int32_t H, int32_t W, float *image, ctx_stream_t stream);
-double ctx_vae_flops(const ctx_vae_t *v);     /* algorithmic FLOPs of the last decode / dry run */
+/* AutoencoderKL.encode behind StableDiffusion.encode_imgs (src/stable_diffusion_depth.py:971-975): image f32 NCHW
+   [B,3,H,W] (the caller applies 2x-1) -> moments f32 NCHW [B, 2*latent_channels, H/8, W/8] = quant_conv(Encoder(x)):
+   mean | logvar of DiagonalGaussianDistribution; `.sample()` (mean + exp(0.5 clamp(logvar,-30,20)) * randn) and the
+   0.18215 factor stay with the caller so that the noise comes from the caller's RNG stream.
+   The parameter table lists post_quant_conv + decoder first (ctx_vae_decoder_param_count entries), then encoder + quant_conv. */
+int32_t ctx_vae_decoder_param_count(const ctx_vae_t *v);
+int64_t ctx_vae_encode_workspace_bytes(const ctx_vae_t *v, int32_t B, int32_t H, int32_t W);
+int32_t ctx_vae_encode(ctx_vae_t *v, const float *image, int32_t B, int32_t H, int32_t W, float *moments, ctx_stream_t stream);
+double ctx_vae_flops(const ctx_vae_t *v);     /* algorithmic FLOPs of the last decode / encode / dry run */
 
 /* Building blocks, exported for unit parity tests (fp16 tensors passed as uint16 bit patterns). */
 /* C[M,N] = A[M,K] @ Wt[N,K]^T (+bias[N]) (+residual[M,N]); K%64==0, N%8==0. */

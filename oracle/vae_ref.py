@@ -1,6 +1,8 @@
 """ORACLE (test infrastructure) — plain-PyTorch fp32 restatement of diffusers 0.27.2 `AutoencoderKL.decode`
 (post_quant_conv + Decoder: conv_in, UNetMidBlock2D with one single-head attention, 4 UpDecoderBlock2D, GroupNorm-SiLU-conv_out)
-as called by src/stable_diffusion_depth.py:976-990.  diffusers / weights are absent offline => PARITY UNPINNED vs diffusers;
+and `AutoencoderKL.encode` (Encoder: conv_in, 4 DownEncoderBlock2D whose Downsample2D is F.pad(x,(0,1,0,1)) + stride-2 conv with
+padding 0, the same mid block, GroupNorm-SiLU-conv_out to 2L channels; quant_conv; moments = mean | logvar)
+as called by src/stable_diffusion_depth.py:971-990.  diffusers / weights are absent offline => PARITY UNPINNED vs diffusers;
 state_dict keys follow diffusers so a real checkpoint would load."""
 import torch
 import torch.nn as nn
@@ -71,6 +73,58 @@ class DecoderRef(nn.Module):
             if hasattr(b, 'upsamplers'):
                 h = b.upsamplers[0].conv(F.interpolate(h, scale_factor=2.0, mode='nearest'))
         return self.conv_out(F.silu(self.conv_norm_out(h)))
+
+
+class EncoderRef(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        ch, g, n = cfg['block_out_channels'], cfg['groups'], len(cfg['block_out_channels'])
+        top = ch[-1]
+        self.conv_in = nn.Conv2d(cfg['out_channels'], ch[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        cur = ch[0]
+        for i in range(n):
+            b = _B()
+            b.resnets = nn.ModuleList([Res(cur if j == 0 else ch[i], ch[i], g) for j in range(cfg['layers_per_block'])])
+            cur = ch[i]
+            if i != n - 1:
+                dn = _B(); dn.conv = nn.Conv2d(cur, cur, 3, stride=2, padding=0)
+                b.downsamplers = nn.ModuleList([dn])
+            self.down_blocks.append(b)
+        self.mid_block = _B()
+        self.mid_block.resnets = nn.ModuleList([Res(top, top, g), Res(top, top, g)])
+        self.mid_block.attentions = nn.ModuleList([Attn(top, g)])
+        self.conv_norm_out = nn.GroupNorm(g, top, eps=1e-6)
+        self.conv_out = nn.Conv2d(top, 2 * cfg['latent_channels'], 3, padding=1)
+
+    def forward(self, x):
+        h = self.conv_in(x)
+        for b in self.down_blocks:
+            for r in b.resnets:
+                h = r(h)
+            if hasattr(b, 'downsamplers'):
+                h = b.downsamplers[0].conv(F.pad(h, (0, 1, 0, 1)))
+        h = self.mid_block.resnets[1](self.mid_block.attentions[0](self.mid_block.resnets[0](h)))
+        return self.conv_out(F.silu(self.conv_norm_out(h)))
+
+
+class AutoencoderKLRef(nn.Module):
+    """decode and encode (moments) with diffusers' key names."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = dict(SD_VAE if cfg is None else cfg)
+        self.cfg = cfg
+        self.post_quant_conv = nn.Conv2d(cfg['latent_channels'], cfg['latent_channels'], 1)
+        self.decoder = DecoderRef(cfg)
+        self.encoder = EncoderRef(cfg)
+        self.quant_conv = nn.Conv2d(2 * cfg['latent_channels'], 2 * cfg['latent_channels'], 1)
+
+    def decode(self, z):
+        return self.decoder(self.post_quant_conv(z))
+
+    def encode_moments(self, x):
+        return self.quant_conv(self.encoder(x))
 
 
 class AutoencoderKLDecodeRef(nn.Module):

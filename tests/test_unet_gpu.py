@@ -403,3 +403,39 @@ def test_vae_decode_vs_oracle(dev, cfgname, h, w):
     print(f"vae {cfgname} {h}x{w}: rel L2 vs fp32 = {r:.3e}")
     assert r < 3e-3, r            # same fp16-storage noise floor as the UNet (tests/test_precision_cpu.py)
     assert torch.equal(got, vae.decode(z.to(dev)).sample)
+
+
+@pytest.mark.parametrize("cfgname,H,W", [("tiny", 128, 128), ("tiny", 64, 32), ("sd", 64, 64)])
+def test_vae_encode_vs_oracle(dev, cfgname, H, W):
+    """VAE encoder engine (stride-2 convs with diffusers' one-sided padding) vs the oracle's fp32 AutoencoderKL.encode moments;
+    a decoder-only checkpoint leaves encode off with a clear error."""
+    from contexture_nerf_amd.vae import AutoencoderKL
+    from contexture_nerf_amd._lib import CtxError
+    from oracle import vae_ref, unet_ref
+    cfg = dict(vae_ref.SD_VAE) if cfgname == "sd" else dict(latent_channels=4, out_channels=3, block_out_channels=(64, 128), layers_per_block=1, groups=32)
+    torch.manual_seed(4)
+    ref = unet_ref.randomize_affine(vae_ref.AutoencoderKLRef(cfg)).eval()
+    vae = AutoencoderKL(cfg, device=dev, init=False)
+    vae.load_state_dict(ref.state_dict())
+    x = torch.rand(1, 3, H, W) * 2 - 1
+    with torch.no_grad():
+        want = ref.encode_moments(x)
+    dist = vae.encode(x.to(dev)).latent_dist
+    got = dist.parameters
+    f = 2 ** (len(cfg['block_out_channels']) - 1)
+    assert got.shape == (1, 8, H // f, W // f) and torch.isfinite(got).all()
+    r = _rel(got, want)
+    print(f"vae encode {cfgname} {H}x{W}: rel L2 vs fp32 = {r:.3e}")
+    assert r < 3e-3, r
+    g = torch.Generator(device=dev).manual_seed(1)
+    smp = dist.sample(generator=g)
+    assert smp.shape == (1, 4, H // f, W // f) and torch.equal(dist.mode(), got[:, :4])
+    # decode still works on the same engine, and a decoder-only state_dict switches encode off
+    z = torch.randn(1, 4, 8, 8)
+    with torch.no_grad():
+        wd = ref.decode(z)
+    assert _rel(vae.decode(z.to(dev)).sample, wd) < 4e-3       # sanity only (test_vae_decode_vs_oracle holds the decode gate)
+    dec_only = {k: v for k, v in ref.state_dict().items() if k.startswith(('decoder.', 'post_quant_conv.'))}
+    vae.load_state_dict(dec_only)
+    with pytest.raises(CtxError):
+        vae.encode(x.to(dev))
