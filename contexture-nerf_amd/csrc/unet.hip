@@ -67,6 +67,15 @@ struct ctx_unet {
     // stats
     int64_t launches[3] = {0, 0, 0};
     double flops[3] = {0, 0, 0};
+    // reference-only self-attention (Zero123++'s RefOnlyNoisedUNet, spec in src/zero123plus.py:127-237): a 'w' pass parks the
+    // attn1 inputs (LayerNorm-1 outputs) of the noised condition latent in a bank, an 'r' pass appends them to the K/V source of
+    // the same attn1 layer for the batch rows >= ref_row0 (is_cfg_guidance: the unconditional row 0 attends without them)
+    struct RefSlot { size_t off; int tokens, C, rows; };
+    int ref_mode = 0;              // 0 off, 1 'w', 2 'r'
+    f16 *ref_bank = nullptr;
+    size_t ref_cursor = 0;         // elements
+    int ref_k = 0, ref_row0 = 0;
+    std::vector<RefSlot> ref_slots;
 
     size_t walloc(size_t n) { size_t o = wtop; wtop += (n + 127) / 128 * 128; return o; }
     size_t add(const std::string &name, std::vector<int64_t> shp, int kind, size_t dst, int a = 0, int b = 0)
@@ -406,10 +415,43 @@ static f16 *run_transformer(ctx_unet *u, const FwdCtx &f, const TrP &t, const f1
     // self attention
     f16 *l = g;   // reuse
     op_ln(u, h0, t.l1g, t.l1b, M, C, l);
-    f16 *qkv = u->allocH((size_t)M * 3 * C);
-    op_gemm(u, l, t.qkv, 0, false, nullptr, M, 3 * C, C, qkv);
-    f16 *a = u->allocH((size_t)M * C);
-    op_attn(u, qkv, qkv + C, qkv + 2 * C, B, S, S, t.heads, 3 * C, 3 * C, a);
+    f16 *a = nullptr;
+    if (u->ref_mode == 2) {
+        // 'r': K/V of a batch row come from [its own tokens ; the condition's tokens parked by the 'w' pass]
+        if (u->ref_k >= (int)u->ref_slots.size() || u->ref_slots[u->ref_k].C != C ||
+            u->ref_slots[u->ref_k].rows != B - u->ref_row0) {
+            u->rc = CTX_E_STATE;
+            ctx_set_error("unet: the reference bank does not match this pass (run the 'w' pass on the condition latent first; layer %d)", u->ref_k);
+            u->top = mark;
+            return out;
+        }
+        const ctx_unet::RefSlot sl = u->ref_slots[u->ref_k++];
+        f16 *q = u->allocH((size_t)M * C);
+        op_gemm(u, l, t.qkv, 0, false, nullptr, M, C, C, q);
+        a = u->allocH((size_t)M * C);
+        f16 *kv = u->allocH((size_t)(S + sl.tokens) * 2 * C);
+        for (int b = 0; b < B; ++b) {
+            const int Sr = b >= u->ref_row0 ? sl.tokens : 0;
+            op_gemm(u, l ? l + (size_t)b * S * C : nullptr, t.qkv + (size_t)C * C, 0, false, nullptr, S, 2 * C, C, kv);
+            if (Sr)
+                op_gemm(u, u->ref_bank ? u->ref_bank + sl.off + (size_t)(b - u->ref_row0) * sl.tokens * C : nullptr,
+                        t.qkv + (size_t)C * C, 0, false, nullptr, Sr, 2 * C, C, kv ? kv + (size_t)S * 2 * C : nullptr);
+            op_attn(u, q ? q + (size_t)b * S * C : nullptr, kv, kv ? kv + C : nullptr, 1, S, S + Sr, t.heads, C, 2 * C,
+                    a ? a + (size_t)b * S * C : nullptr);
+        }
+    } else {
+        if (u->ref_mode == 1) {    // 'w': park this layer's attn1 input
+            ctx_unet::RefSlot sl; sl.off = u->ref_cursor; sl.tokens = S; sl.C = C; sl.rows = B;
+            u->ref_slots.push_back(sl);
+            u->ref_cursor += (size_t)M * C;
+            if (!u->dry && u->rc == 0 && u->ref_bank)
+                (void)hipMemcpyAsync(u->ref_bank + sl.off, l, (size_t)M * C * 2, hipMemcpyDeviceToDevice, u->s);
+        }
+        f16 *qkv = u->allocH((size_t)M * 3 * C);
+        op_gemm(u, l, t.qkv, 0, false, nullptr, M, 3 * C, C, qkv);
+        a = u->allocH((size_t)M * C);
+        op_attn(u, qkv, qkv + C, qkv + 2 * C, B, S, S, t.heads, 3 * C, 3 * C, a);
+    }
     f16 *h1 = u->allocH((size_t)M * C);
     op_gemm(u, a, t.o1w, t.o1b, true, h0, M, C, C, h1);
     // cross attention
@@ -438,6 +480,8 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
     const int n = c.n_levels, lpb = c.layers_per_block;
     const int *ch = c.block_out_channels;
     u->top = 0; u->peak = 0; u->rc = 0;
+    u->ref_k = 0; u->ref_cursor = 0;
+    if (u->ref_mode == 1) u->ref_slots.clear();
     for (int k = 0; k < 3; ++k) { u->launches[k] = 0; u->flops[k] = 0; }
     FwdCtx f; f.B = B; f.L = L;
     f.gn_stats = u->alloc((size_t)ctx_groupnorm_ws_bytes(B, c.groups));
@@ -564,6 +608,52 @@ extern "C" int32_t ctx_unet_forward(ctx_unet_t *u, const float *sample, const fl
     u->s = (hipStream_t)stream;
     u->dry = false;
     return unet_run(u, sample, timestep, ctx, B, H, W, ctx_len, out);
+}
+
+// ---- reference-only attention passes ----------------------------------------------------------------------------------
+extern "C" int64_t ctx_unet_ref_bank_bytes(const ctx_unet_t *cu, int32_t B, int32_t H, int32_t W)
+{
+    ctx_unet *u = const_cast<ctx_unet *>(cu);
+    if (!u || check_dims(u, B, H, W, 1)) return -1;
+    std::vector<ctx_unet::RefSlot> keep = u->ref_slots;
+    bool was = u->dry; int mode = u->ref_mode;
+    u->dry = true; u->ref_mode = 1;
+    unet_run(u, nullptr, nullptr, nullptr, B, H, W, 1, nullptr);
+    int64_t n = (int64_t)u->ref_cursor * 2 + 256;
+    u->dry = was; u->ref_mode = mode; u->ref_slots = keep;
+    return n;
+}
+
+extern "C" int64_t ctx_unet_workspace_bytes_ref(const ctx_unet_t *cu, int32_t B, int32_t H, int32_t W, int32_t ctx_len, int32_t mode,
+                                                int32_t ref_row0)
+{
+    ctx_unet *u = const_cast<ctx_unet *>(cu);
+    if (!u || check_dims(u, B, H, W, ctx_len) || mode < 1 || mode > 2 || ref_row0 < 0 || ref_row0 >= B) return -1;
+    std::vector<ctx_unet::RefSlot> keep = u->ref_slots;
+    bool was = u->dry; int m0 = u->ref_mode, r0 = u->ref_row0;
+    u->dry = true; u->ref_mode = mode; u->ref_row0 = ref_row0;
+    int rc = unet_run(u, nullptr, nullptr, nullptr, B, H, W, ctx_len, nullptr);
+    int64_t n = rc ? -1 : (int64_t)u->peak + 4096;
+    u->dry = was; u->ref_mode = m0; u->ref_row0 = r0;
+    if (mode == 1) u->ref_slots = keep;
+    return n;
+}
+
+extern "C" int32_t ctx_unet_forward_ref(ctx_unet_t *u, const float *sample, const float *timestep, const float *ctx, int32_t B,
+                                        int32_t H, int32_t W, int32_t ctx_len, int32_t mode, void *bank, int32_t ref_row0, float *out,
+                                        ctx_stream_t stream)
+{
+    CTX_REQUIRE(u && sample && timestep && ctx && out && bank, "unet_forward_ref: null pointer");
+    CTX_REQUIRE(u->W && u->ws, "unet_forward_ref: ctx_unet_bind() first");
+    CTX_REQUIRE(mode == 1 || mode == 2, "unet_forward_ref: mode %d (1 = 'w' park the attn1 inputs, 2 = 'r' attend to them)", mode);
+    CTX_REQUIRE(ref_row0 >= 0 && ref_row0 < B, "unet_forward_ref: ref_row0=%d outside [0, B)", ref_row0);
+    if (check_dims(u, B, H, W, ctx_len)) return CTX_E_ARG;
+    u->s = (hipStream_t)stream;
+    u->dry = false;
+    u->ref_mode = mode; u->ref_bank = (f16 *)bank; u->ref_row0 = mode == 2 ? ref_row0 : 0;
+    int rc = unet_run(u, sample, timestep, ctx, B, H, W, ctx_len, out);
+    u->ref_mode = 0; u->ref_bank = nullptr; u->ref_row0 = 0;
+    return rc;
 }
 
 extern "C" int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops)

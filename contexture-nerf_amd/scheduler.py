@@ -121,3 +121,4 @@ class DDPMScheduler:
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
 
     add_noise = PNDMScheduler.add_noise
+    scale_model_input = PNDMScheduler.scale_model_input

@@ -156,6 +156,42 @@ class UNet2DConditionModel:
     def __call__(self, sample, timestep, encoder_hidden_states=None, **kw):
         return self.forward(sample, timestep, encoder_hidden_states)
 
+    def forward_ref(self, sample, timestep, encoder_hidden_states, mode, bank=None, ref_row0=0):
+        """Reference-only attention passes (src/zero123plus.py:127-237): mode 'w' parks the attn1 inputs of this forward in a
+        bank (returned with the output), mode 'r' appends the parked tokens of `bank` to the self-attention K/V of the batch rows
+        >= ref_row0.  -> ({'sample': out}, bank)."""
+        m = {'w': 1, 'r': 2}.get(mode)
+        if m is None:
+            raise L.CtxError(f"unet.forward_ref: mode {mode!r} (expected 'w' or 'r')")
+        x = L.f32c(sample, self.device)
+        ctx = L.f32c(encoder_hidden_states, self.device)
+        B, Cin, H, W = x.shape
+        if Cin != self.in_channels or ctx.shape[0] != B or ctx.shape[2] != self.config['cross_attention_dim']:
+            raise L.CtxError(f"unet.forward_ref: sample {tuple(x.shape)} / encoder_hidden_states {tuple(ctx.shape)} do not fit")
+        Lc = ctx.shape[1]
+        if m == 1:
+            nb = self._lib.ctx_unet_ref_bank_bytes(self._h, B, H, W)
+            if nb < 0:
+                raise L.CtxError(self._lib.ctx_last_error().decode())
+            if bank is None or bank.numel() < nb:
+                bank = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        elif bank is None:
+            raise L.CtxError("unet.forward_ref: mode 'r' needs the bank of a 'w' pass")
+        need = self._lib.ctx_unet_workspace_bytes_ref(self._h, B, H, W, Lc, m, ref_row0 if m == 2 else 0)
+        if need < 0:
+            raise L.CtxError(self._lib.ctx_last_error().decode())
+        if self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._bind()
+        self._ws_key = None
+        if self._t is None:
+            self._t = torch.empty(1, dtype=torch.float32, device=self.device)
+        self._t.fill_(float(timestep))
+        out = torch.empty(B, self.config['out_channels'], H, W, device=self.device)
+        L.check(self._lib.ctx_unet_forward_ref(self._h, L.ptr(x, torch.float32, "sample"), L.ptr(self._t), L.ptr(ctx), B, H, W, Lc, m,
+                                               L.ptr(bank), ref_row0, L.ptr(out), L.stream()))
+        return {'sample': out}, bank
+
     def forward(self, sample, timestep, encoder_hidden_states):
         x = L.f32c(sample, self.device)
         ctx = L.f32c(encoder_hidden_states, self.device)

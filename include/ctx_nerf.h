@@ -179,6 +179,20 @@ int32_t ctx_unet_set_param(ctx_unet_t *u, int32_t i, const float *src, ctx_strea
    -> out[B,Cout,H,W] f32 NCHW.  Computes in fp16 with fp32 accumulation/statistics. */
 int32_t ctx_unet_forward(ctx_unet_t *u, const float *sample, const float *timestep, const float *ctx,
                          int32_t B, int32_t H, int32_t W, int32_t ctx_len, float *out, ctx_stream_t stream);
+/* Reference-only self-attention (Zero123++'s RefOnlyNoisedUNet / ReferenceOnlyAttnProc; the reference keeps the spec in
+   src/zero123plus.py:127-237 and drives it from src/training/trainer.py:644-907).
+   mode 1 ('w'): an ordinary forward over the noised condition latent that also parks every attn1 input (the LayerNorm-1 output,
+                 [B, tokens, C] fp16 per layer) in `bank` (ctx_unet_ref_bank_bytes(u, B, H, W) bytes).
+   mode 2 ('r'): forward whose attn1 layers use [own tokens ; parked tokens] as the K/V source for the batch rows >= ref_row0
+                 (is_cfg_guidance => ref_row0 = 1: the unconditional row attends without the reference); row b reads the parked
+                 row b - ref_row0, so the 'w' pass must have had B - ref_row0 rows.  The bank layout is private to the engine
+                 that wrote it.  Workspace: ctx_unet_workspace_bytes_ref (for mode 2 call it after the 'w' pass). */
+int64_t ctx_unet_ref_bank_bytes(const ctx_unet_t *u, int32_t B, int32_t H, int32_t W);
+int64_t ctx_unet_workspace_bytes_ref(const ctx_unet_t *u, int32_t B, int32_t H, int32_t W, int32_t ctx_len, int32_t mode,
+                                     int32_t ref_row0);
+int32_t ctx_unet_forward_ref(ctx_unet_t *u, const float *sample, const float *timestep, const float *ctx,
+                             int32_t B, int32_t H, int32_t W, int32_t ctx_len, int32_t mode, void *bank, int32_t ref_row0,
+                             float *out, ctx_stream_t stream);
 /* Per-kernel accounting of the last forward: number of launches and algorithmic FLOPs by class
    (0 gemm/conv MFMA, 1 attention MFMA, 2 other). */
 int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops);

@@ -113,7 +113,19 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, ctx):
-        x = x + self.attn1(self.norm1(x))
+        n = self.norm1(x)
+        st = getattr(self, '_ref_state', None)      # reference-only attention (src/zero123plus.py:127-161), see ref_only_forward
+        if st is None:
+            a = self.attn1(n)
+        elif st['mode'] == 'w':
+            st['bank'][id(self)] = n
+            a = self.attn1(n)
+        else:
+            r0 = st['row0']
+            outs = [self.attn1(n[:r0])] if r0 else []
+            outs.append(self.attn1(n[r0:], torch.cat([n[r0:], st['bank'][id(self)]], dim=1)))
+            a = torch.cat(outs)
+        x = x + a
         x = x + self.attn2(self.norm2(x), ctx)
         return x + self.ff(self.norm3(x))
 
@@ -366,3 +378,22 @@ def forward_fp16_storage(model, sample, timestep, ctx, q=_h, q_res=_h, q_w=_h):
             if hasattr(blk, 'upsamplers'):
                 hh = q_res(blk.upsamplers[0](q(hh)))
         return {'sample': mq.conv_out(q(F.silu(mq.conv_norm_out(hh))))}
+
+
+def ref_only_forward(model, sample, timestep, ctx, noisy_cond_lat, is_cfg_guidance):
+    """RefOnlyNoisedUNet.forward of src/zero123plus.py:164-237 on the fp32 oracle UNet (the condition latent arrives already
+    noised: the noise draw and the scheduler are the caller's): 'w' pass over the condition parks each attn1's input
+    (with is_cfg_guidance only the conditional context row is used), 'r' pass appends them along the token axis to the K/V
+    source of the same attn1, the unconditional batch row 0 attending without them."""
+    blocks = [m for m in model.modules() if isinstance(m, BasicTransformerBlock)]
+    st = {'mode': 'w', 'bank': {}, 'row0': 0}
+    for b in blocks:
+        b._ref_state = st
+    try:
+        model(noisy_cond_lat, timestep, ctx[1:] if is_cfg_guidance else ctx)
+        st['mode'] = 'r'; st['row0'] = 1 if is_cfg_guidance else 0
+        out = model(sample, timestep, ctx)
+    finally:
+        for b in blocks:
+            del b._ref_state
+    return out

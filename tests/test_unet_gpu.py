@@ -439,3 +439,39 @@ def test_vae_encode_vs_oracle(dev, cfgname, H, W):
     vae.load_state_dict(dec_only)
     with pytest.raises(CtxError):
         vae.encode(x.to(dev))
+
+
+@pytest.mark.parametrize("cfg_guidance", [True, False])
+def test_ref_only_attention_vs_oracle(dev, cfg_guidance):
+    """Zero123++'s reference-only self-attention as two engine passes ('w' over the noised condition latent, 'r' over a
+    non-square sample with the extra K/V tokens) vs the oracle's restatement of src/zero123plus.py:127-237."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel
+    from contexture_nerf_amd.zero123plus import RefOnlyNoisedUNet
+    from contexture_nerf_amd.scheduler import DDPMScheduler
+    from oracle import unet_ref
+    cfg = unet_ref.tiny_config(in_channels=4)
+    torch.manual_seed(6)
+    ref = unet_ref.randomize_affine(unet_ref.UNet2DConditionModelRef(cfg)).eval()
+    net = UNet2DConditionModel(cfg, device=dev, init=False)
+    net.load_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(8)
+    B = 2 if cfg_guidance else 1
+    x = torch.randn(B, 4, 16, 8, generator=g)                  # the 3x2 view grid is not square (120 x 80 at full size)
+    cond = 3 * torch.randn(1, 4, 16, 16, generator=g)          # noised condition latent: 256 extra tokens at level 0, 64 at level 1
+    ctx = torch.randn(B, 9, cfg['cross_attention_dim'], generator=g)
+    with torch.no_grad():
+        want = unet_ref.ref_only_forward(ref, x, torch.tensor(321.0), ctx, cond, cfg_guidance)['sample']
+        plain = ref(x, torch.tensor(321.0), ctx)['sample']
+    # engine passes directly
+    _, bank = net.forward_ref(cond.to(dev), 321.0, (ctx[1:] if cfg_guidance else ctx).to(dev), 'w')
+    got = net.forward_ref(x.to(dev), 321.0, ctx.to(dev), 'r', bank=bank, ref_row0=1 if cfg_guidance else 0)[0]['sample']
+    r = _rel(got, want)
+    print(f"ref-only cfg={cfg_guidance}: rel L2 vs fp32 = {r:.3e}; reference tokens move the output by {_rel(plain.to(dev), want):.3e}")
+    assert r < 3e-3, r
+    assert _rel(plain.to(dev), want) > 4 * r                    # the parked tokens matter (well above the fp16 noise)
+    # a plain forward afterwards is unaffected by the passes
+    assert _rel(net(x.to(dev), 321.0, ctx.to(dev))['sample'], plain) < 3e-3
+    # the host mirror of RefOnlyNoisedUNet: same two passes behind the reference's call shape (its own noise draw on cond_lat)
+    wrap = RefOnlyNoisedUNet(net, DDPMScheduler(), DDPMScheduler()).eval()
+    out = wrap(x.to(dev), torch.tensor([321]), ctx.to(dev), cross_attention_kwargs=dict(cond_lat=cond.to(dev), is_cfg_guidance=cfg_guidance))
+    assert out['sample'].shape == x.shape and torch.isfinite(out['sample']).all()
