@@ -52,6 +52,11 @@ SIGNATURES = {
     "ctx_unet_bind": (_i32, [_vp, _vp, _vp, _i64]),
     "ctx_unet_set_param": (_i32, [_vp, _i32, _vp, _vp]),
     "ctx_unet_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ctx_controlnet_create": (_vp, [_vp, _i32]),
+    "ctx_controlnet_residual_bytes": (_i64, [_vp, _i32, _i32, _i32]),
+    "ctx_controlnet_cond_cache_bytes": (_i64, [_vp, _i32, _i32, _i32]),
+    "ctx_controlnet_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ctx_unet_set_residuals": (_i32, [_vp, _vp, C.c_float]),
     "ctx_unet_ref_bank_bytes": (_i64, [_vp, _i32, _i32, _i32]),
     "ctx_unet_workspace_bytes_ref": (_i64, [_vp, _i32, _i32, _i32, _i32, _i32, _i32]),
     "ctx_unet_forward_ref": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),

@@ -76,6 +76,22 @@ struct ctx_unet {
     size_t ref_cursor = 0;         // elements
     int ref_k = 0, ref_row0 = 0;
     std::vector<RefSlot> ref_slots;
+    // ControlNet (diffusers ControlNetModel.from_unet: the UNet's conv_in / time embedding / down blocks / mid block + a
+    // conditioning-image embedding + 1x1 "zero" convolutions; Zero123++'s DepthControlUNet, spec in src/zero123plus.py:260-298)
+    bool is_controlnet = false;
+    int cond_channels = 3;
+    struct CondConv { size_t w, b; int cin, cout, stride; };
+    std::vector<CondConv> cond_convs;          // conv_in, blocks.0..5, conv_out
+    std::vector<size_t> zc_w, zc_b;            // controlnet_down_blocks.i (one per skip tensor)
+    std::vector<int> zc_c;
+    size_t zm_w = 0, zm_b = 0;                 // controlnet_mid_block
+    const float *cn_cond = nullptr;            // this pass's conditioning image f32 NCHW [B, cond_channels, 8H, 8W]
+    f16 *cn_cache = nullptr;                   // caller-held [B,H,W,256] output of the embedding's few-channel layers
+    bool cn_cache_valid = false;               // true: the image is the one the cache was computed from (it does not change per step)
+    f16 *cn_out = nullptr;                     // ControlNet pass: residuals out (skip order, then mid), fp16 NHWC
+    // main UNet pass: residuals to add (same layout) and their scale
+    const f16 *add_res = nullptr;
+    float add_scale = 1.0f;
 
     size_t walloc(size_t n) { size_t o = wtop; wtop += (n + 127) / 128 * 128; return o; }
     size_t add(const std::string &name, std::vector<int64_t> shp, int kind, size_t dst, int a = 0, int b = 0)
@@ -148,7 +164,7 @@ static void add_transformer(ctx_unet *u, const std::string &p, int C, int heads,
     t.pow_ = u->lin(p + ".proj_out.weight", C, C); t.pob = u->vec(p + ".proj_out.bias", C);
 }
 
-extern "C" ctx_unet_t *ctx_unet_create(const ctx_unet_config_t *cfg)
+static ctx_unet_t *unet_create_impl(const ctx_unet_config_t *cfg, bool controlnet, int cond_channels)
 {
     if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->in_channels > 8 || cfg->out_channels > 4 ||
         cfg->groups > 64 || cfg->layers_per_block < 1 || cfg->layers_per_block > 4 || cfg->cross_attention_dim % 64) {
@@ -168,16 +184,18 @@ extern "C" ctx_unet_t *ctx_unet_create(const ctx_unet_config_t *cfg)
     u->temb_dim = ch[0] * 4;
     // total time_emb_proj rows
     int rows = 0;
+    u->is_controlnet = controlnet; u->cond_channels = cond_channels;
     for (int i = 0; i < n; ++i) rows += lpb * ch[i];
     rows += 2 * ch[n - 1];
-    for (int i = 0; i < n; ++i) rows += (lpb + 1) * ch[n - 1 - i];
+    if (!controlnet)
+        for (int i = 0; i < n; ++i) rows += (lpb + 1) * ch[n - 1 - i];
     u->tpw = u->walloc((size_t)rows * u->temb_dim);
     u->tpb = u->walloc(rows);
     {
         int kvr = 2 * ch[n - 1];                                        // mid block
         for (int i = 0; i < n; ++i) {
             if (cfg->down_attn[i]) kvr += lpb * 2 * ch[i];
-            if (cfg->up_attn[i]) kvr += (lpb + 1) * 2 * ch[n - 1 - i];
+            if (cfg->up_attn[i] && !controlnet) kvr += (lpb + 1) * 2 * ch[n - 1 - i];
         }
         u->kv_rows_total = kvr;
         u->kvw = u->walloc((size_t)kvr * cfg->cross_attention_dim);
@@ -213,33 +231,65 @@ extern "C" ctx_unet_t *ctx_unet_create(const ctx_unet_config_t *cfg)
         add_transformer(u, "mid_block.attentions.0", ch[n - 1], cfg->heads[n - 1], L.tr[0]);
         add_resnet(u, "mid_block.resnets.1", ch[n - 1], ch[n - 1], L.res[1]);
     }
-    u->up.resize(n);
-    out = ch[n - 1];
-    for (int i = 0; i < n; ++i) {
-        LevelP &L = u->up[i];
-        int prev = out; out = ch[n - 1 - i];
-        int inp = ch[n - 1 - (i + 1 < n ? i + 1 : n - 1)];
-        std::string p = "up_blocks." + std::to_string(i);
-        L.res.resize(lpb + 1);
-        for (int j = 0; j <= lpb; ++j) {
-            int skip = j == lpb ? inp : out;
-            int rin = j == 0 ? prev : out;
-            add_resnet(u, p + ".resnets." + std::to_string(j), rin + skip, out, L.res[j]);
+    if (!controlnet) {
+        u->up.resize(n);
+        out = ch[n - 1];
+        for (int i = 0; i < n; ++i) {
+            LevelP &L = u->up[i];
+            int prev = out; out = ch[n - 1 - i];
+            int inp = ch[n - 1 - (i + 1 < n ? i + 1 : n - 1)];
+            std::string p = "up_blocks." + std::to_string(i);
+            L.res.resize(lpb + 1);
+            for (int j = 0; j <= lpb; ++j) {
+                int skip = j == lpb ? inp : out;
+                int rin = j == 0 ? prev : out;
+                add_resnet(u, p + ".resnets." + std::to_string(j), rin + skip, out, L.res[j]);
+            }
+            L.has_attn = cfg->up_attn[i] != 0;
+            if (L.has_attn) {
+                L.tr.resize(lpb + 1);
+                for (int j = 0; j <= lpb; ++j) add_transformer(u, p + ".attentions." + std::to_string(j), out, cfg->heads[n - 1 - i], L.tr[j]);
+            }
+            if (i != n - 1) {
+                L.has_sampler = true; L.sc = out;
+                L.sw = u->add(p + ".upsamplers.0.conv.weight", {out, out, 3, 3}, PK_CONV3, u->walloc((size_t)out * out * 9), out, out);
+                L.sb = u->vec(p + ".upsamplers.0.conv.bias", out);
+            }
         }
-        L.has_attn = cfg->up_attn[i] != 0;
-        if (L.has_attn) {
-            L.tr.resize(lpb + 1);
-            for (int j = 0; j <= lpb; ++j) add_transformer(u, p + ".attentions." + std::to_string(j), out, cfg->heads[n - 1 - i], L.tr[j]);
+        u->cng = u->vec("conv_norm_out.weight", ch[0]); u->cnb = u->vec("conv_norm_out.bias", ch[0]);
+        u->cow = u->add("conv_out.weight", {cfg->out_channels, ch[0], 3, 3}, PK_CONV3, u->walloc((size_t)cfg->out_channels * ch[0] * 9), cfg->out_channels, ch[0]);
+        u->cob = u->vec("conv_out.bias", cfg->out_channels);
+    } else {
+        // controlnet_cond_embedding: conv_in(cond -> 16) SiLU, [conv(c -> c) SiLU, conv(c -> c', stride 2) SiLU] x 3, conv_out(256 -> ch0)
+        const int cc[4] = {16, 32, 96, 256};
+        const std::string e = "controlnet_cond_embedding";
+        auto addc = [&](const std::string &name, int cin, int cout, int stride) {
+            ctx_unet::CondConv c; c.cin = cin; c.cout = cout; c.stride = stride;
+            c.w = u->add(name + ".weight", {cout, cin, 3, 3}, PK_CONV3, u->walloc((size_t)cout * cin * 9), cout, cin);
+            c.b = u->vec(name + ".bias", cout);
+            u->cond_convs.push_back(c);
+        };
+        addc(e + ".conv_in", cond_channels, cc[0], 1);
+        for (int i = 0; i < 3; ++i) {
+            addc(e + ".blocks." + std::to_string(2 * i), cc[i], cc[i], 1);
+            addc(e + ".blocks." + std::to_string(2 * i + 1), cc[i], cc[i + 1], 2);
         }
-        if (i != n - 1) {
-            L.has_sampler = true; L.sc = out;
-            L.sw = u->add(p + ".upsamplers.0.conv.weight", {out, out, 3, 3}, PK_CONV3, u->walloc((size_t)out * out * 9), out, out);
-            L.sb = u->vec(p + ".upsamplers.0.conv.bias", out);
+        addc(e + ".conv_out", cc[3], ch[0], 1);
+        // zero convolutions, one per skip tensor: conv_in output, every resnet(+attention) output, every downsampler output
+        std::vector<int> skc; skc.push_back(ch[0]);
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < lpb; ++j) skc.push_back(ch[i]);
+            if (i != n - 1) skc.push_back(ch[i]);
         }
+        for (size_t k = 0; k < skc.size(); ++k) {
+            std::string p = "controlnet_down_blocks." + std::to_string(k);
+            u->zc_w.push_back(u->add(p + ".weight", {skc[k], skc[k], 1, 1}, PK_COPY, u->walloc((size_t)skc[k] * skc[k])));
+            u->zc_b.push_back(u->vec(p + ".bias", skc[k]));
+            u->zc_c.push_back(skc[k]);
+        }
+        u->zm_w = u->add("controlnet_mid_block.weight", {ch[n - 1], ch[n - 1], 1, 1}, PK_COPY, u->walloc((size_t)ch[n - 1] * ch[n - 1]));
+        u->zm_b = u->vec("controlnet_mid_block.bias", ch[n - 1]);
     }
-    u->cng = u->vec("conv_norm_out.weight", ch[0]); u->cnb = u->vec("conv_norm_out.bias", ch[0]);
-    u->cow = u->add("conv_out.weight", {cfg->out_channels, ch[0], 3, 3}, PK_CONV3, u->walloc((size_t)cfg->out_channels * ch[0] * 9), cfg->out_channels, ch[0]);
-    u->cob = u->vec("conv_out.bias", cfg->out_channels);
     if (u->kv_rows != u->kv_rows_total) {
         ctx_set_error("unet_create: internal cross-attention K/V row count mismatch %d != %d", u->kv_rows, u->kv_rows_total);
         delete u;
@@ -253,6 +303,12 @@ extern "C" ctx_unet_t *ctx_unet_create(const ctx_unet_config_t *cfg)
     return u;
 }
 
+extern "C" ctx_unet_t *ctx_unet_create(const ctx_unet_config_t *cfg) { return unet_create_impl(cfg, false, 0); }
+extern "C" ctx_unet_t *ctx_controlnet_create(const ctx_unet_config_t *cfg, int32_t cond_channels)
+{
+    if (cond_channels < 1 || cond_channels > 8) { ctx_set_error("controlnet_create: cond_channels=%d outside [1,8]", cond_channels); return nullptr; }
+    return unet_create_impl(cfg, true, cond_channels);
+}
 extern "C" void ctx_unet_destroy(ctx_unet_t *u) { delete u; }
 extern "C" int32_t ctx_unet_param_count(const ctx_unet_t *u) { return u ? (int32_t)u->params.size() : 0; }
 extern "C" const char *ctx_unet_param_name(const ctx_unet_t *u, int32_t i)
@@ -324,6 +380,55 @@ extern "C" int32_t ctx_unet_set_param(ctx_unet_t *u, int32_t i, const float *src
     }
     CTX_CHECK_LAUNCH("unet_set_param");
     return CTX_OK;
+}
+
+// 3x3 convolution (pad 1, stride 1 | 2) for the few-channel layers of ControlNet's conditioning embedding (3 -> 16 -> 16 -> 32
+// -> 32 -> 96 -> 96 -> 256; they run once per conditioning image, not per denoise step).  One thread = one output pixel x 8 output
+// channels; input either the f32 NCHW image (first layer) or f16 NHWC; weights [Cout][3][3][Cin] f16; optional SiLU; f16 NHWC out.
+__global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x32, const f16 *__restrict__ x16, const f16 *__restrict__ w,
+                                                    const f16 *__restrict__ bias, int B, int H, int W, int Cin, int Cout, int stride,
+                                                    int silu, f16 *__restrict__ y)
+{
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1, o8n = Cout / 8;
+    const int64_t total = (int64_t)B * Ho * Wo * o8n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int o8 = (int)(i % o8n);
+        const int64_t pix = i / o8n;
+        const int b = (int)(pix / ((int64_t)Ho * Wo)), p = (int)(pix % ((int64_t)Ho * Wo));
+        const int oy = p / Wo, ox = p % Wo;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (float)bias[o8 * 8 + j];
+        for (int t = 0; t < 9; ++t) {
+            const int iy = oy * stride + t / 3 - 1, ix = ox * stride + t % 3 - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            for (int c = 0; c < Cin; ++c) {
+                const float v = x32 ? (float)(f16)x32[(((int64_t)b * Cin + c) * H + iy) * W + ix]
+                                    : (float)x16[(((int64_t)b * H + iy) * W + ix) * Cin + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v * (float)w[(((int64_t)(o8 * 8 + j)) * 9 + t) * Cin + c];
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[j];
+            if (silu) v = v / (1.0f + __expf(-v));
+            o[j] = (f16)v;
+        }
+        *(f16x8 *)(y + pix * Cout + o8 * 8) = o;
+    }
+}
+
+// dst += scale * src (fp16, 8 per thread); the residual injection of the ControlNet outputs
+__global__ __launch_bounds__(256) void k_add_scaled_f16(f16 *__restrict__ dst, const f16 *__restrict__ src, float scale, int64_t n8)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        f16x8 a = *(const f16x8 *)(dst + i * 8), b = *(const f16x8 *)(src + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (f16)((float)a[j] + scale * (float)b[j]);
+        *(f16x8 *)(dst + i * 8) = a;
+    }
 }
 
 // ---- op wrappers (skip launches on a dry run, keep accounting identical) ---------------------------------
@@ -507,6 +612,40 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
     f16 *x = u->allocH((size_t)B * h * w * ch[0]);
     note(u, 2, 2.0 * B * h * w * ch[0] * c.in_channels * 9); RUN(ctx_conv_in_f16(sample, u->W + u->ciw, u->W + u->cib, B, c.in_channels, h, w, ch[0], x, u->s));
 
+    auto add_scaled = [&](f16 *dst, const f16 *src, float scale, size_t n) {
+        note(u, 2, 0);
+        if (!u->dry && u->rc == 0)
+            hipLaunchKernelGGL(k_add_scaled_f16, dim3((unsigned)std::min<int64_t>(cdiv64((int64_t)n / 8, 256), 4096)), dim3(256), 0, u->s, dst, src,
+                               scale, (int64_t)n / 8);
+    };
+    if (u->is_controlnet) {
+        // sample = conv_in(sample) + controlnet_cond_embedding(cond): the conditioning image is 8x the latent grid
+        size_t mark = u->top;
+        int eh = 8 * H, ew = 8 * W;
+        const f16 *cur16 = nullptr;
+        const size_t nconv = u->cond_convs.size();
+        for (size_t k = 0; k + 1 < nconv; ++k) {
+            const ctx_unet::CondConv &cc = u->cond_convs[k];
+            int oh = (eh - 1) / cc.stride + 1, ow = (ew - 1) / cc.stride + 1;
+            const bool last = k + 2 == nconv;                   // its output is what the cache holds
+            f16 *o = (last && u->cn_cache) ? u->cn_cache : u->allocH((size_t)B * oh * ow * cc.cout);
+            if (!u->cn_cache_valid) {
+                note(u, 2, 2.0 * B * oh * ow * cc.cout * cc.cin * 9);
+                if (!u->dry && u->rc == 0) {
+                    int64_t items = (int64_t)B * oh * ow * (cc.cout / 8);
+                    hipLaunchKernelGGL(k_conv_small, dim3((unsigned)std::min<int64_t>(cdiv64(items, 256), 65535)), dim3(256), 0, u->s,
+                                       k == 0 ? u->cn_cond : nullptr, cur16, u->W + cc.w, u->W + cc.b, B, eh, ew, cc.cin, cc.cout, cc.stride, 1, o);
+                }
+            }
+            cur16 = o; eh = oh; ew = ow;
+        }
+        if (eh != h || ew != w) { ctx_set_error("controlnet: conditioning embedding grid %dx%d != latent grid %dx%d", eh, ew, h, w); return CTX_E_ARG; }
+        const ctx_unet::CondConv &co = u->cond_convs.back();
+        f16 *emb = u->allocH((size_t)B * h * w * ch[0]);
+        op_conv(u, cur16, co.w, co.b, nullptr, 0, x, B, h, w, co.cin, ch[0], 1, 0, emb);       // + conv_in(sample) as the residual operand
+        if (!u->dry && u->rc == 0) (void)hipMemcpyAsync(x, emb, (size_t)B * h * w * ch[0] * 2, hipMemcpyDeviceToDevice, u->s);
+        u->top = mark;
+    }
     struct Skip { f16 *p; int C, h, w; };
     std::vector<Skip> skips;
     skips.push_back({x, ch[0], h, w});
@@ -534,6 +673,30 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
             skips.push_back({x, cur, h, w});
         }
     }
+    size_t res_off = 0;                        // running element offset into the residual buffers (skip order, then mid)
+    if (u->is_controlnet) {
+        // zero convolutions of the skip tensors -> residuals (the conditioning scale is applied where they are added)
+        if (skips.size() != u->zc_w.size()) { ctx_set_error("controlnet: %zu skip tensors but %zu zero convolutions", skips.size(), u->zc_w.size()); return CTX_E_STATE; }
+        for (size_t k = 0; k < skips.size(); ++k) {
+            const Skip &sk = skips[k];
+            const size_t nel = (size_t)B * sk.h * sk.w * sk.C;
+            op_gemm(u, sk.p, u->zc_w[k], u->zc_b[k], true, nullptr, B * sk.h * sk.w, sk.C, sk.C, u->cn_out ? u->cn_out + res_off : nullptr);
+            res_off += nel;
+        }
+    } else if (u->add_res) {
+        // down_block_additional_residuals: added to the skip copies once the down path has consumed the originals
+        for (size_t k = 0; k < skips.size(); ++k) {
+            Skip &sk = skips[k];
+            const size_t nel = (size_t)B * sk.h * sk.w * sk.C;
+            if (sk.p == x) {                   // the last skip tensor is also the mid block's input, which stays as it is
+                f16 *cp = u->allocH(nel);
+                if (!u->dry && u->rc == 0) (void)hipMemcpyAsync(cp, sk.p, nel * 2, hipMemcpyDeviceToDevice, u->s);
+                sk.p = cp;
+            }
+            add_scaled(sk.p, u->add_res + res_off, u->add_scale, nel);
+            res_off += nel;
+        }
+    }
     {
         f16 *o1 = u->allocH((size_t)B * h * w * cur);
         run_resnet(u, f, u->mid.res[0], x, h, w, o1);
@@ -543,6 +706,17 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
         run_resnet(u, f, u->mid.res[1], o2, h, w, o3);
         x = o3;
     }
+    if (u->is_controlnet) {
+        op_gemm(u, x, u->zm_w, u->zm_b, true, nullptr, B * h * w, cur, cur, u->cn_out ? u->cn_out + res_off : nullptr);
+        res_off += (size_t)B * h * w * cur;
+        u->ref_cursor = res_off;               // element count of the residual buffer (read by the size query)
+        if (!u->dry && u->rc == 0) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { ctx_set_error("controlnet_forward: launch failed: %s", hipGetErrorString(e)); return CTX_E_LAUNCH; }
+        }
+        return u->rc;
+    }
+    if (u->add_res) add_scaled(x, u->add_res + res_off, u->add_scale, (size_t)B * h * w * cur);
     for (int i = 0; i < n; ++i) {
         LevelP &Lv = u->up[i];
         for (int j = 0; j <= lpb; ++j) {
@@ -608,6 +782,47 @@ extern "C" int32_t ctx_unet_forward(ctx_unet_t *u, const float *sample, const fl
     u->s = (hipStream_t)stream;
     u->dry = false;
     return unet_run(u, sample, timestep, ctx, B, H, W, ctx_len, out);
+}
+
+// ---- ControlNet -----------------------------------------------------------------------------------------------------------
+extern "C" int64_t ctx_controlnet_residual_bytes(const ctx_unet_t *cu, int32_t B, int32_t H, int32_t W)
+{
+    ctx_unet *u = const_cast<ctx_unet *>(cu);
+    if (!u || !u->is_controlnet || check_dims(u, B, H, W, 1)) return -1;
+    bool was = u->dry;
+    u->dry = true;
+    int rc = unet_run(u, nullptr, nullptr, nullptr, B, H, W, 1, nullptr);
+    u->dry = was;
+    return rc ? -1 : (int64_t)u->ref_cursor * 2 + 256;
+}
+
+extern "C" int64_t ctx_controlnet_cond_cache_bytes(const ctx_unet_t *u, int32_t B, int32_t H, int32_t W)
+{
+    if (!u || !u->is_controlnet || B < 1 || H < 1 || W < 1 || u->cond_convs.size() < 2) return -1;
+    return (int64_t)B * H * W * u->cond_convs[u->cond_convs.size() - 2].cout * 2 + 256;
+}
+
+extern "C" int32_t ctx_controlnet_forward(ctx_unet_t *u, const float *sample, const float *timestep, const float *ctx, const float *cond,
+                                          void *cond_cache, int32_t cache_valid, int32_t B, int32_t H, int32_t W, int32_t ctx_len,
+                                          void *residuals, ctx_stream_t stream)
+{
+    CTX_REQUIRE(u && sample && timestep && ctx && cond && residuals, "controlnet_forward: null pointer");
+    CTX_REQUIRE(!cache_valid || cond_cache, "controlnet_forward: cache_valid without a cond_cache buffer");
+    CTX_REQUIRE(u->is_controlnet, "controlnet_forward: the handle is a UNet (create it with ctx_controlnet_create)");
+    CTX_REQUIRE(u->W && u->ws, "controlnet_forward: ctx_unet_bind() first");
+    if (check_dims(u, B, H, W, ctx_len)) return CTX_E_ARG;
+    u->s = (hipStream_t)stream; u->dry = false;
+    u->cn_cond = cond; u->cn_out = (f16 *)residuals; u->cn_cache = (f16 *)cond_cache; u->cn_cache_valid = cache_valid != 0;
+    int rc = unet_run(u, sample, timestep, ctx, B, H, W, ctx_len, nullptr);
+    u->cn_cond = nullptr; u->cn_out = nullptr; u->cn_cache = nullptr; u->cn_cache_valid = false;
+    return rc;
+}
+
+extern "C" int32_t ctx_unet_set_residuals(ctx_unet_t *u, const void *residuals, float scale)
+{
+    CTX_REQUIRE(u && !u->is_controlnet, "unet_set_residuals: need a UNet handle");
+    u->add_res = (const f16 *)residuals; u->add_scale = scale;
+    return CTX_OK;
 }
 
 // ---- reference-only attention passes ----------------------------------------------------------------------------------

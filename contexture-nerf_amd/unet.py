@@ -153,8 +153,30 @@ class UNet2DConditionModel:
             out[name] = (n.value, f.value)
         return out
 
-    def __call__(self, sample, timestep, encoder_hidden_states=None, **kw):
-        return self.forward(sample, timestep, encoder_hidden_states)
+    def __call__(self, sample, timestep, encoder_hidden_states=None, down_block_additional_residuals=None,
+                 mid_block_additional_residual=None, **kw):
+        if down_block_additional_residuals is None:
+            return self.forward(sample, timestep, encoder_hidden_states)
+        with self.residuals(down_block_additional_residuals):
+            return self.forward(sample, timestep, encoder_hidden_states)
+
+    def residuals(self, res):
+        """Context manager: the forwards inside add a ControlNetModel's residuals (`ControlResiduals`) to the skip tensors and the
+        mid-block output (diffusers' down_block_additional_residuals / mid_block_additional_residual)."""
+        unet = self
+
+        class _Scope:
+            def __enter__(s):
+                if not isinstance(res, ControlResiduals):
+                    raise L.CtxError("unet: additional residuals must come from contexture_nerf_amd.unet.ControlNetModel")
+                L.check(unet._lib.ctx_unet_set_residuals(unet._h, L.ptr(res.buffer), float(res.scale)))
+                unet._ws_key = None                # the injection needs one more skip-sized buffer: re-query the workspace
+
+            def __exit__(s, *a):
+                L.check(unet._lib.ctx_unet_set_residuals(unet._h, None, 1.0))
+                unet._ws_key = None
+                return False
+        return _Scope()
 
     def forward_ref(self, sample, timestep, encoder_hidden_states, mode, bank=None, ref_row0=0):
         """Reference-only attention passes (src/zero123plus.py:127-237): mode 'w' parks the attn1 inputs of this forward in a
@@ -220,6 +242,82 @@ class UNet2DConditionModel:
         L.check(self._lib.ctx_unet_forward(self._h, L.ptr(x, torch.float32, "sample"), L.ptr(t), L.ptr(ctx), B, H, W, Lc,
                                            L.ptr(out), L.stream()))
         return {'sample': out}
+
+
+class ControlResiduals(list):
+    """What ControlNetModel returns in place of diffusers' tuple of tensors: `.buffer` holds every residual (fp16, engine layout),
+    `.scale` the conditioning scale the UNet applies when it adds them; the list items are [B,h,w,C] fp16 views for inspection
+    (skip order, the mid-block residual last)."""
+    buffer = None
+    scale = 1.0
+
+
+class ControlNetModel(UNet2DConditionModel):
+    """diffusers.ControlNetModel (`from_unet` topology: conditioning channels 16-32-96-256) on the HIP engine; the reference loads
+    "sudo-ai/controlnet-zp11-depth-v1" with conditioning_scale=2 (src/training/trainer.py:302-304).  Call shape:
+    controlnet(sample, t, encoder_hidden_states=, controlnet_cond=, conditioning_scale=, return_dict=False) -> (down, mid)."""
+
+    def __init__(self, config=None, device="cuda:0", seed=0, init=True, conditioning_channels=3):
+        self.conditioning_channels = conditioning_channels
+        super().__init__(config, device=device, seed=seed, init=init)
+        self._res = None
+        self._cond_cache, self._cond_key = None, None      # embedding of the last conditioning image (same tensor, same version)
+
+    def _create_handle(self):
+        cfg = self.config
+        c = UNetConfig(cfg['in_channels'], cfg['out_channels'], len(cfg['block_out_channels']),
+                       _pad4(cfg['block_out_channels']), _pad4(cfg['heads']), _pad4(cfg['down_attn']),
+                       _pad4(cfg['up_attn']), cfg['layers_per_block'], cfg['cross_attention_dim'], cfg['groups'],
+                       cfg['norm_eps'])
+        h = self._lib.ctx_controlnet_create(C.byref(c), self.conditioning_channels)
+        if not h:
+            raise L.CtxError("ctx_controlnet_create: " + self._lib.ctx_last_error().decode())
+        return h
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, controlnet_cond=None, conditioning_scale=1.0,
+                 return_dict=False, **kw):
+        x = L.f32c(sample, self.device)
+        ctx = L.f32c(encoder_hidden_states, self.device)
+        cond = L.f32c(controlnet_cond, self.device)
+        B, Cin, H, W = x.shape
+        if Cin != self.in_channels or ctx.shape[0] != B or tuple(cond.shape) != (B, self.conditioning_channels, 8 * H, 8 * W):
+            raise L.CtxError(f"controlnet: sample {tuple(x.shape)}, encoder_hidden_states {tuple(ctx.shape)}, controlnet_cond "
+                             f"{tuple(cond.shape)} do not fit (the conditioning image is 8x the latent grid)")
+        Lc = ctx.shape[1]
+        need = self.workspace_bytes(B, H, W, Lc)
+        if self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._bind()
+        nb = self._lib.ctx_controlnet_residual_bytes(self._h, B, H, W)
+        if self._res is None or self._res.numel() < nb:
+            self._res = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        if self._t is None:
+            self._t = torch.empty(1, dtype=torch.float32, device=self.device)
+        self._t.fill_(float(timestep))
+        cb = self._lib.ctx_controlnet_cond_cache_bytes(self._h, B, H, W)
+        if self._cond_cache is None or self._cond_cache.numel() < cb:
+            self._cond_cache, self._cond_key = torch.empty(cb, dtype=torch.uint8, device=self.device), None
+        key = (controlnet_cond.data_ptr(), controlnet_cond._version, tuple(controlnet_cond.shape))
+        valid = int(key == self._cond_key)                  # the depth image does not change between the steps of one denoise
+        L.check(self._lib.ctx_controlnet_forward(self._h, L.ptr(x, torch.float32, "sample"), L.ptr(self._t), L.ptr(ctx),
+                                                 L.ptr(cond, torch.float32, "controlnet_cond"), L.ptr(self._cond_cache), valid, B, H, W, Lc,
+                                                 L.ptr(self._res), L.stream()))
+        self._cond_key = key
+        out = ControlResiduals()
+        out.buffer, out.scale = self._res, float(conditioning_scale)
+        half = self._res.view(torch.float16)
+        ch, lpb, n = self.config['block_out_channels'], self.config['layers_per_block'], len(self.config['block_out_channels'])
+        shapes, h, w = [(H, W, ch[0])], H, W
+        for i in range(n):
+            shapes += [(h, w, ch[i])] * lpb
+            if i != n - 1:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                shapes.append((h, w, ch[i]))
+        shapes.append((h, w, ch[-1]))                                     # mid
+        off = 0
+        for (hh, ww, cc) in shapes:
+            out.append(half[off:off + B * hh * ww * cc].view(B, hh, ww, cc)); off += B * hh * ww * cc
+        return out, out[-1]
 
 
 def smoke_check(dev):

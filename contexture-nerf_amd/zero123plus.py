@@ -7,7 +7,9 @@ src/training/trainer.py:296-315); what is built here is the part that sits on th
       (the unconditional row of a CFG batch attends without them, `is_cfg_guidance`),
   scale_latents / unscale_latents / scale_image / unscale_image (:240-257; mirrors in utils.py).
 
-Not built: DepthControlUNet (ControlNet residuals, :260-298) and the pipeline __call__ (:748-833).
+  DepthControlUNet  (:260-298): a ControlNetModel engine whose residuals the UNet adds to its skip tensors / mid output.
+
+Not built: the pipeline __call__ (:748-833) and its schedulers' sampling loop.
 """
 import torch
 from . import _lib as L
@@ -36,8 +38,6 @@ class RefOnlyNoisedUNet(torch.nn.Module):
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, *args, cross_attention_kwargs,
                 down_block_res_samples=None, mid_block_res_sample=None, **kwargs):
-        if down_block_res_samples is not None or mid_block_res_sample is not None:
-            raise L.CtxError("RefOnlyNoisedUNet: ControlNet residuals (DepthControlUNet) are not built on the HIP engine")
         cond_lat = cross_attention_kwargs['cond_lat']
         is_cfg_guidance = cross_attention_kwargs.get('is_cfg_guidance', False)
         noise = torch.randn_like(cond_lat)
@@ -47,6 +47,34 @@ class RefOnlyNoisedUNet(torch.nn.Module):
         noisy_cond_lat = sched.scale_model_input(noisy_cond_lat, t)
         ref_dict = {}
         self.forward_cond(noisy_cond_lat, float(t[0]), encoder_hidden_states, class_labels, ref_dict, is_cfg_guidance)
-        out, _ = self.unet.forward_ref(sample, float(t[0]), encoder_hidden_states, 'r', bank=ref_dict.pop('bank'),
-                                       ref_row0=1 if is_cfg_guidance else 0)
+        bank = ref_dict.pop('bank')
+        if down_block_res_samples is not None:
+            with self.unet.residuals(down_block_res_samples):
+                out, _ = self.unet.forward_ref(sample, float(t[0]), encoder_hidden_states, 'r', bank=bank,
+                                               ref_row0=1 if is_cfg_guidance else 0)
+        else:
+            out, _ = self.unet.forward_ref(sample, float(t[0]), encoder_hidden_states, 'r', bank=bank, ref_row0=1 if is_cfg_guidance else 0)
         return out
+
+
+class DepthControlUNet(torch.nn.Module):
+    def __init__(self, unet, controlnet=None, conditioning_scale=1.0):
+        super().__init__()
+        self.unet = unet
+        if controlnet is None:
+            from .unet import ControlNetModel
+            inner = unet.unet
+            controlnet = ControlNetModel(inner.config, device=inner.device)     # from_unet topology, fresh (seeded) weights offline
+        self.controlnet = controlnet
+        self.conditioning_scale = conditioning_scale
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, *args, cross_attention_kwargs, **kwargs):
+        cross_attention_kwargs = dict(cross_attention_kwargs)
+        control_depth = cross_attention_kwargs.pop('control_depth')
+        t = float(timestep.reshape(-1)[0]) if isinstance(timestep, torch.Tensor) else float(timestep)
+        down_block_res_samples, mid_block_res_sample = self.controlnet(
+            sample, t, encoder_hidden_states=encoder_hidden_states, controlnet_cond=control_depth,
+            conditioning_scale=self.conditioning_scale, return_dict=False)
+        return self.unet(sample, timestep, encoder_hidden_states=encoder_hidden_states,
+                         down_block_res_samples=down_block_res_samples, mid_block_res_sample=mid_block_res_sample,
+                         cross_attention_kwargs=cross_attention_kwargs)

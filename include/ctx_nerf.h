@@ -193,6 +193,22 @@ int64_t ctx_unet_workspace_bytes_ref(const ctx_unet_t *u, int32_t B, int32_t H, 
 int32_t ctx_unet_forward_ref(ctx_unet_t *u, const float *sample, const float *timestep, const float *ctx,
                              int32_t B, int32_t H, int32_t W, int32_t ctx_len, int32_t mode, void *bank, int32_t ref_row0,
                              float *out, ctx_stream_t stream);
+/* ControlNet (diffusers ControlNetModel.from_unet; Zero123++'s DepthControlUNet, spec in src/zero123plus.py:260-298, loaded at
+   src/training/trainer.py:302-304): an engine with the UNet's conv_in / time embedding / down blocks / mid block, the
+   conditioning-image embedding (channels 16-32-96-256, three stride-2 steps: the image is 8x the latent grid) and the 1x1 zero
+   convolutions.  ctx_controlnet_forward writes the residuals (one per skip tensor, then the mid block; fp16, engine layout,
+   ctx_controlnet_residual_bytes) — UNSCALED; ctx_unet_set_residuals hands them to a UNet engine of the same configuration, which
+   adds `scale` x residual to its skip tensors and mid-block output in the following forwards (NULL switches it off).
+   Parameter names are diffusers' ControlNetModel state_dict keys; the size / bind / set_param / destroy calls are ctx_unet_*. */
+ctx_unet_t *ctx_controlnet_create(const ctx_unet_config_t *cfg, int32_t cond_channels);
+int64_t ctx_controlnet_residual_bytes(const ctx_unet_t *cn, int32_t B, int32_t H, int32_t W);
+/* cond_cache (nullable; ctx_controlnet_cond_cache_bytes): holds the output of the embedding's few-channel layers, which depends
+   only on the conditioning image; pass cache_valid = 1 while the image is unchanged (every denoise step after the first). */
+int64_t ctx_controlnet_cond_cache_bytes(const ctx_unet_t *cn, int32_t B, int32_t H, int32_t W);
+int32_t ctx_controlnet_forward(ctx_unet_t *cn, const float *sample, const float *timestep, const float *ctx,
+                               const float *cond /*[B,cond_channels,8H,8W] f32 NCHW*/, void *cond_cache, int32_t cache_valid,
+                               int32_t B, int32_t H, int32_t W, int32_t ctx_len, void *residuals, ctx_stream_t stream);
+int32_t ctx_unet_set_residuals(ctx_unet_t *u, const void *residuals /*nullable*/, float scale);
 /* Per-kernel accounting of the last forward: number of launches and algorithmic FLOPs by class
    (0 gemm/conv MFMA, 1 attention MFMA, 2 other). */
 int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops);

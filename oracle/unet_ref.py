@@ -212,7 +212,10 @@ class UNet2DConditionModelRef(nn.Module):
         self.conv_norm_out = nn.GroupNorm(g, ch[0], eps=eps)
         self.conv_out = nn.Conv2d(ch[0], cfg['out_channels'], 3, padding=1)
 
-    def forward(self, sample, timestep, encoder_hidden_states):
+    def forward(self, sample, timestep, encoder_hidden_states, down_block_additional_residuals=None,
+                mid_block_additional_residual=None):
+        """diffusers semantics of the ControlNet inputs: the residuals are added to the collected skip tensors after the down
+        path, and to the mid-block output."""
         t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(sample.shape[0])
         temb = self.time_embedding(timestep_embedding(t, self.cfg['block_out_channels'][0]))
         ctx = encoder_hidden_states
@@ -227,9 +230,13 @@ class UNet2DConditionModelRef(nn.Module):
             if hasattr(blk, 'downsamplers'):
                 h = blk.downsamplers[0](h)
                 skips.append(h)
+        if down_block_additional_residuals is not None:
+            skips = [a + b for a, b in zip(skips, down_block_additional_residuals)]
         h = self.mid_block.resnets[0](h, temb)
         h = self.mid_block.attentions[0](h, ctx)
         h = self.mid_block.resnets[1](h, temb)
+        if mid_block_additional_residual is not None:
+            h = h + mid_block_additional_residual
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
                 h = r(torch.cat([h, skips.pop()], dim=1), temb)
@@ -239,6 +246,59 @@ class UNet2DConditionModelRef(nn.Module):
                 h = blk.upsamplers[0](h)
         h = self.conv_out(F.silu(self.conv_norm_out(h)))
         return {'sample': h}
+
+
+class ControlNetModelRef(nn.Module):
+    """diffusers 0.27.2 ControlNetModel with the `from_unet` topology (PARITY UNPINNED vs diffusers, like the UNet): the UNet's
+    conv_in / time_embedding / down_blocks / mid_block, ControlNetConditioningEmbedding (conv_in, [conv, conv stride 2] x 3 with
+    SiLU after each, conv_out; channels 16-32-96-256) added to conv_in(sample), and one 1x1 convolution per skip tensor + one
+    for the mid block; outputs multiplied by conditioning_scale.  Spec of its use: src/zero123plus.py:260-298."""
+
+    def __init__(self, cfg, conditioning_channels=3, emb_channels=(16, 32, 96, 256)):
+        super().__init__()
+        u = UNet2DConditionModelRef(cfg)
+        self.cfg = u.cfg
+        self.conv_in, self.time_embedding, self.down_blocks, self.mid_block = u.conv_in, u.time_embedding, u.down_blocks, u.mid_block
+        ch = cfg['block_out_channels']
+        e = Block()
+        e.conv_in = nn.Conv2d(conditioning_channels, emb_channels[0], 3, padding=1)
+        e.blocks = nn.ModuleList()
+        for i in range(len(emb_channels) - 1):
+            e.blocks.append(nn.Conv2d(emb_channels[i], emb_channels[i], 3, padding=1))
+            e.blocks.append(nn.Conv2d(emb_channels[i], emb_channels[i + 1], 3, padding=1, stride=2))
+        e.conv_out = nn.Conv2d(emb_channels[-1], ch[0], 3, padding=1)
+        self.controlnet_cond_embedding = e
+        skc = [ch[0]]
+        for i, c in enumerate(ch):
+            skc += [c] * cfg['layers_per_block']
+            if i != len(ch) - 1:
+                skc.append(c)
+        self.controlnet_down_blocks = nn.ModuleList([nn.Conv2d(c, c, 1) for c in skc])
+        self.controlnet_mid_block = nn.Conv2d(ch[-1], ch[-1], 1)
+
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0):
+        t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(sample.shape[0])
+        temb = self.time_embedding(timestep_embedding(t, self.cfg['block_out_channels'][0]))
+        e = self.controlnet_cond_embedding
+        c = F.silu(e.conv_in(controlnet_cond))
+        for blk in e.blocks:
+            c = F.silu(blk(c))
+        h = self.conv_in(sample) + e.conv_out(c)
+        skips = [h]
+        for blk in self.down_blocks:
+            for j, r in enumerate(blk.resnets):
+                h = r(h, temb)
+                if hasattr(blk, 'attentions'):
+                    h = blk.attentions[j](h, encoder_hidden_states)
+                skips.append(h)
+            if hasattr(blk, 'downsamplers'):
+                h = blk.downsamplers[0](h)
+                skips.append(h)
+        h = self.mid_block.resnets[0](h, temb)
+        h = self.mid_block.attentions[0](h, encoder_hidden_states)
+        h = self.mid_block.resnets[1](h, temb)
+        down = [z(s) * conditioning_scale for z, s in zip(self.controlnet_down_blocks, skips)]
+        return down, self.controlnet_mid_block(h) * conditioning_scale
 
 
 def randomize_affine(model, seed=0, scale=0.1):
