@@ -59,3 +59,38 @@ class Mesh:
         verts[:, 1] += dy
         mesh.vertices = verts
         return mesh
+
+
+def _write_png_rgb(path, rgb):
+    """Minimal 8-bit RGB PNG writer (zlib only): the albedo map of export_mesh."""
+    import struct, zlib
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, c = rgb.shape
+    assert c == 3
+    raw = b''.join(b'\x00' + rgb[i].tobytes() for i in range(h))
+
+    def chunk(tag, data):
+        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, 'wb') as fp:
+        fp.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 2, 0, 0, 0)) +
+                 chunk(b'IDAT', zlib.compress(raw, 6)) + chunk(b'IEND', b''))
+
+
+def write_textured_obj(path, vertices, faces, uvs, face_uvs_idx, albedo_rgb_u8, name=''):
+    """The on-disk result of the paint loop, in the layout the reference's TexturedMeshModel.export_mesh produces
+    (src/models/textured_mesh.py:418-474): `{name}albedo.png` (the [T,T,3] uint8 atlas as is, v not flipped),
+    `{name}mesh.obj` (mtllib line, `v x y z`, `vt u v`, `usemtl mat0`, `f v/vt v/vt v/vt` 1-based) and `{name}mesh.mtl`
+    (material mat0 with map_Kd -> the albedo map)."""
+    os.makedirs(path, exist_ok=True)
+    _write_png_rgb(os.path.join(path, f'{name}albedo.png'), albedo_rgb_u8)
+    v_np, f_np = np.asarray(vertices), np.asarray(faces).astype(np.int64)
+    vt_np, ft_np = np.asarray(uvs), np.asarray(face_uvs_idx).astype(np.int64)
+    with open(os.path.join(path, f'{name}mesh.obj'), 'w') as fp:
+        fp.write(f'mtllib {name}mesh.mtl \n')
+        fp.writelines(f'v {v[0]} {v[1]} {v[2]} \n' for v in v_np)
+        fp.writelines(f'vt {t[0]} {t[1]} \n' for t in vt_np)
+        fp.write('usemtl mat0 \n')
+        fp.writelines(f'f {a[0] + 1}/{b[0] + 1} {a[1] + 1}/{b[1] + 1} {a[2] + 1}/{b[2] + 1} \n' for a, b in zip(f_np, ft_np))
+    with open(os.path.join(path, f'{name}mesh.mtl'), 'w') as fp:
+        fp.write('newmtl mat0 \nKa 1.000000 1.000000 1.000000 \nKd 1.000000 1.000000 1.000000 \nKs 0.000000 0.000000 0.000000 \n'
+                 f'Tr 1.000000 \nillum 1 \nNs 0.000000 \nmap_Kd {name}albedo.png \n')

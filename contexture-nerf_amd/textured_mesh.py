@@ -80,6 +80,16 @@ class TexturedMeshModel(torch.nn.Module):
         """-> (texture [1,3,res,res] in [0,1], mlp_output [res*res,3]); uv grid, embedding, MLP and (tanh+1)/2 fused."""
         return self.texture_mlp.texture_map(self.texture_resolution)
 
+    def export_mesh(self, path, texture=None):
+        """src/models/textured_mesh.py:418-474: albedo.png + mesh.obj + mesh.mtl.  texture (optional [1,3,T,T] in [0,1]): the
+        painted atlas (ConTEXTure.paint's merged UV scatter) instead of the texture field's current output."""
+        from .mesh import write_textured_obj
+        with torch.no_grad():
+            tex = self.get_texture_map()[0] if texture is None else texture
+            colors = (tex.permute(0, 2, 3, 1).contiguous().clamp(0, 1)[0] * 255).to(torch.uint8).cpu().numpy()
+        write_textured_obj(path, self.mesh.vertices.detach().cpu().numpy(), self.mesh.faces.cpu().numpy(),
+                           self.vt.detach().cpu().numpy(), self.ft.detach().cpu().numpy(), colors)
+
     def _angles(self, v):
         if v is None:
             return None

@@ -161,4 +161,18 @@ class ConTEXTure:
                 contrib += self.project_back_scatter(self._last['render_cache'], rgb, masks[j:j + 1] & (obj_mask > 0))
             j += len(grp)
         atlas, coverage = D.merge_atlas(contrib, self.group)
+        self.atlas, self.atlas_coverage = atlas, coverage
         return atlas, coverage
+
+    def export(self, path=None):
+        """The outputs the reference writes after painting (src/training/trainer.py:954-968 -> export_mesh): mesh.obj / mesh.mtl /
+        albedo.png with the painted atlas (rank 0 only; uncovered texels keep the texture field's colour)."""
+        if D.dist.is_initialized() and D.dist.get_rank(self.group) != 0:
+            return None
+        path = str(self.cfg.log.exp_dir / 'mesh') if path is None else str(path)
+        with torch.no_grad():
+            base = self.mesh_model.get_texture_map()[0]
+            cov = (self.atlas_coverage > 0)[None, None].to(base.dtype)
+            tex = base * (1 - cov) + self.atlas[None, :3] * cov
+        self.mesh_model.export_mesh(path, texture=tex)
+        return path

@@ -111,6 +111,15 @@ def test_trainer_view_weights_paint_and_atlas(dev, meshes):
     assert torch.allclose(atlas1, atlas, rtol=1e-5, atol=1e-6)          # float-atomic scatter order only
     assert 0.05 < float((cov > 0).float().mean()) <= 1.0
     assert float(atlas.min()) >= 0 and float(atlas.max()) <= 1.0 + 1e-5
+    # outputs on disk (export_mesh layout): the OBJ reads back, the albedo map has the atlas resolution
+    import struct, tempfile, os
+    from contexture_nerf_amd import kal
+    with tempfile.TemporaryDirectory() as td:
+        p = tr.export(os.path.join(td, 'mesh'))
+        mm = kal.io.obj.import_mesh(os.path.join(p, 'mesh.obj'))
+        assert mm.faces.shape == tr.mesh_model.mesh.faces.shape and mm.uvs.shape[1] == 2
+        raw = open(os.path.join(p, 'albedo.png'), 'rb').read()
+        assert struct.unpack('>II', raw[16:24]) == (128, 128) and os.path.exists(os.path.join(p, 'mesh.mtl'))
 
 
 def test_volume_render_and_refine(dev):
