@@ -188,14 +188,17 @@ def test_tuned_plans_against_torch(dev):
         if conv:
             Cin = K // 9
             st, up = (2 if flags & 1 else 1), (1 if flags & 2 else 0)
-            # recover the input grid: M = Bn * Ho * Wo, square, Bn = 2 (CFG pair) or 1; Ho = (H << up - 1) // st + 1
-            Ho = int(round((M // 2) ** 0.5)); Bn = 2
-            if 2 * Ho * Ho != M:
-                Ho = int(round(M ** 0.5)); Bn = 1
-            assert Bn * Ho * Ho == M
-            H = Ho // 2 if up else (Ho * 2 if st == 2 else Ho)
-            x = torch.randn(Bn, H, H, Cin, generator=g, device=dev).half()
-            cb = (Bn, H, H, Cin, flags)
+            # recover the output grid from M = Bn * Ho * Wo: square with Bn = 2 (CFG pair) or 1, or the 3:2 view grid of
+            # Zero123++ (120 x 80 and its halvings) with Bn = 2
+            Ho = Wo = int(round((M // 2) ** 0.5)); Bn = 2
+            if Bn * Ho * Wo != M:
+                Ho = Wo = int(round(M ** 0.5)); Bn = 1
+            if Bn * Ho * Wo != M:
+                k = int(round((M / 12) ** 0.5)); Ho, Wo, Bn = 3 * k, 2 * k, 2
+            assert Bn * Ho * Wo == M, (M, N, K)
+            H, W_ = (Ho // 2, Wo // 2) if up else ((Ho * 2, Wo * 2) if st == 2 else (Ho, Wo))
+            x = torch.randn(Bn, H, W_, Cin, generator=g, device=dev).half()
+            cb = (Bn, H, W_, Cin, flags)
         else:
             x = torch.randn(M, K, generator=g, device=dev).half()
             cb = (0, 0, 0, 0, 0)

@@ -21,12 +21,13 @@ lib = L.load(); dev = torch.device('cuda:0')
 
 
 def layer_list(Lt, Bn=2):
-    """(conv, M, N, K, flags, epi, desc) of the SD2-depth UNet at latent Lt x Lt, batch Bn."""
+    """(conv, M, N, K, flags, epi, desc) of the SD2-depth UNet at latent Lt (int: square, or (H, W)), batch Bn."""
     out = set()
     ch = [320, 640, 1280, 1280]
-    res = [Lt, Lt // 2, Lt // 4, Lt // 8]
+    Hh, Ww = (Lt, Lt) if isinstance(Lt, int) else Lt
+    res = [(Hh >> k, Ww >> k) for k in range(4)]
     def conv(r, cout, cin, flags=0):
-        out.add((1, (Bn, r, r), cout, cin, flags, 0))
+        out.add((1, (Bn, r[0], r[1]), cout, cin, flags, 0))
     def lin(M, N, K, epi=0):
         out.add((0, M, N, K, 0, epi))
     # resnets: (level, cin, cout)
@@ -34,20 +35,20 @@ def layer_list(Lt, Bn=2):
         c = ch[lv]; r = res[lv]
         for cin in set(cins):
             conv(r, c, cin)
-            if cin != c: lin(Bn * r * r, c, cin)
+            if cin != c: lin(Bn * r[0] * r[1], c, cin)
         conv(r, c, c)
     for lv in range(3):
         conv(res[lv], ch[lv], ch[lv], 1)                      # downsample (stride 2), input at res[lv]
         conv(res[lv + 1], ch[lv + 1] if lv < 2 else 1280, ch[lv + 1] if lv < 2 else 1280, 2)   # upsample conv, input at res[lv+1]
     for lv in range(4):
-        c = ch[lv]; M = Bn * res[lv] * res[lv]
+        c = ch[lv]; M = Bn * res[lv][0] * res[lv][1]
         lin(M, c, c); lin(M, 3 * c, c); lin(M, 8 * c, c, 1); lin(M, c, 4 * c)
     lin(77 * Bn, 24960, 1024)
     return sorted(out, key=str)
 
 
 shapes = []
-for Lt in [int(x) for x in args.latents.split(",")]:
+for Lt in [(tuple(int(v) for v in x.split("x")) if "x" in x else int(x)) for x in args.latents.split(",")]:
     for s_ in layer_list(Lt, args.batch):
         if s_ not in shapes: shapes.append(s_)
 g = torch.Generator(device=dev).manual_seed(0)
