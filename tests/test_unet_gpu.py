@@ -527,3 +527,38 @@ def test_controlnet_residuals_vs_oracle(dev):
     out = stack(x.to(dev), torch.tensor([77]), ctx.to(dev),
                 cross_attention_kwargs=dict(cond_lat=cond_lat.to(dev), control_depth=depth.to(dev), is_cfg_guidance=True))
     assert out['sample'].shape == x.shape and torch.isfinite(out['sample']).all()
+
+
+def test_new_entry_points_fail_loudly(dev):
+    """error behaviour of this round's entry points: wrong shapes / wrong order raise CtxError with a message, nothing is
+    silently computed on a fallback path."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel, ControlNetModel
+    from contexture_nerf_amd.vae import AutoencoderKL
+    from contexture_nerf_amd import run_nerf_helpers as rnh
+    from contexture_nerf_amd._lib import CtxError
+    from oracle import unet_ref
+    cfg = unet_ref.tiny_config(in_channels=4)
+    net = UNet2DConditionModel(cfg, device=dev, seed=1)
+    x = torch.randn(2, 4, 16, 8, device=dev); ctx = torch.randn(2, 9, cfg['cross_attention_dim'], device=dev)
+    with pytest.raises(CtxError, match="bank"):
+        net.forward_ref(x, 10.0, ctx, 'r')                               # no bank at all
+    other = UNet2DConditionModel(cfg, device=dev, seed=2)
+    _, bank = other.forward_ref(x[:1], 10.0, ctx[:1], 'w')
+    with pytest.raises(CtxError, match="reference bank"):
+        net.forward_ref(x, 10.0, ctx, 'r', bank=bank, ref_row0=1)        # this engine never ran a 'w' pass
+    with pytest.raises(CtxError):
+        net.forward_ref(x, 10.0, ctx, 'q')
+    cnet = ControlNetModel(cfg, device=dev, seed=3)
+    with pytest.raises(CtxError, match="8x the latent grid"):
+        cnet(x, 10.0, encoder_hidden_states=ctx, controlnet_cond=torch.rand(2, 3, 64, 64, device=dev))
+    with pytest.raises(CtxError):
+        net(x, 10.0, encoder_hidden_states=ctx, down_block_additional_residuals=[torch.zeros(1, device=dev)])
+    vae = AutoencoderKL(dict(latent_channels=4, out_channels=3, block_out_channels=(64, 128), layers_per_block=1, groups=32), device=dev)
+    with pytest.raises(CtxError, match="multiples"):
+        vae.encode(torch.rand(1, 3, 30, 30, device=dev))
+    with pytest.raises(CtxError):
+        rnh.NeRF2D(D=8, W=256, input_ch=70, output_ch=3, skips=[4]).to(dev).packed()      # beyond the fused kernel's envelope
+    field = rnh.NeRF2D(D=8, W=64, input_ch=63, output_ch=4, skips=[4]).to(dev)
+    with pytest.raises(CtxError):
+        with torch.no_grad():
+            field.texture_map(16)                                         # the atlas grid is a 2-D input; this field is 3-D
