@@ -122,3 +122,88 @@ class DDPMScheduler:
 
     add_noise = PNDMScheduler.add_noise
     scale_model_input = PNDMScheduler.scale_model_input
+
+
+class EulerAncestralDiscreteScheduler:
+    """diffusers 0.27.2 EulerAncestralDiscreteScheduler as Zero123++ samples with it (`val_sched` of RefOnlyNoisedUNet and the
+    pipeline's scheduler, src/zero123plus.py:164-237, 411-746): sigma_t = sqrt((1 - abar_t) / abar_t), model input scaled by
+    1 / sqrt(sigma^2 + 1), epsilon or v prediction, ancestral step with fresh noise.  Host-side tensor arithmetic only.
+    PARITY UNPINNED vs diffusers (absent offline); oracle/scheduler.py restates the same published algorithm in numpy.
+    `set_timesteps(timesteps=[...])` takes an explicit schedule (the SDS loop denoises one step at its DreamTime t,
+    src/training/trainer.py:785-795)."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 prediction_type="v_prediction", timestep_spacing="linspace", steps_offset=0, **kw):
+        if beta_schedule != "scaled_linear":
+            raise ValueError(f"beta_schedule {beta_schedule!r} is not implemented")
+        self.num_train_timesteps, self.prediction_type = num_train_timesteps, prediction_type
+        self.timestep_spacing, self.steps_offset = timestep_spacing, steps_offset
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self._sig_all = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
+        self.set_timesteps(num_train_timesteps)
+
+    def _sigma_at(self, t):
+        """linear interpolation of the training sigmas at (fractional) timesteps t."""
+        t = torch.as_tensor(t, dtype=torch.float64)
+        lo = t.floor().clamp(0, self.num_train_timesteps - 1).long()
+        hi = (lo + 1).clamp(max=self.num_train_timesteps - 1)
+        w = (t - lo.double()).clamp(0, 1)
+        s = self._sig_all.double()
+        return ((1 - w) * s[lo] + w * s[hi]).float()
+
+    def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None):
+        T = self.num_train_timesteps
+        if timesteps is not None:
+            ts = torch.as_tensor(timesteps, dtype=torch.float64).reshape(-1)
+        elif self.timestep_spacing == "linspace":
+            ts = torch.linspace(0, T - 1, num_inference_steps, dtype=torch.float64).flip(0)
+        elif self.timestep_spacing == "leading":
+            ts = (torch.arange(0, num_inference_steps, dtype=torch.float64) * (T // num_inference_steps)).round().flip(0) + self.steps_offset
+        elif self.timestep_spacing == "trailing":
+            ts = torch.arange(T, 0, -T / num_inference_steps, dtype=torch.float64).round() - 1
+        else:
+            raise ValueError(f"timestep_spacing {self.timestep_spacing!r}")
+        self.num_inference_steps = len(ts)
+        self.timesteps = ts.float()
+        self.sigmas = torch.cat([self._sigma_at(ts), torch.zeros(1)])
+        self._step_index = None
+
+    @property
+    def init_noise_sigma(self):
+        m = self.sigmas.max()
+        return m if self.timestep_spacing in ("linspace", "trailing") else (m ** 2 + 1) ** 0.5
+
+    def _index(self, timestep):
+        t = float(timestep.reshape(-1)[0]) if isinstance(timestep, torch.Tensor) else float(timestep)
+        idx = (self.timesteps - t).abs().argmin().item()
+        if abs(float(self.timesteps[idx]) - t) > 1e-3:
+            raise ValueError(f"timestep {t} is not on the schedule set by set_timesteps")
+        return idx
+
+    def scale_model_input(self, sample, timestep):
+        sigma = self.sigmas[self._index(timestep)].to(sample.device, sample.dtype)
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        sig = torch.stack([self.sigmas[self._index(t)] for t in torch.as_tensor(timesteps).reshape(-1)]).to(original_samples.device, original_samples.dtype)
+        while sig.dim() < original_samples.dim():
+            sig = sig.unsqueeze(-1)
+        return original_samples + noise * sig
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+        i = self._index(timestep)
+        sigma, sigma_to = float(self.sigmas[i]), float(self.sigmas[i + 1])
+        if self.prediction_type == "epsilon":
+            pred_original = sample - sigma * model_output
+        elif self.prediction_type == "v_prediction":
+            pred_original = model_output * (-sigma / (sigma ** 2 + 1) ** 0.5) + sample / (sigma ** 2 + 1)
+        else:
+            raise ValueError(f"prediction_type {self.prediction_type!r}")
+        sigma_up = (sigma_to ** 2 * (sigma ** 2 - sigma_to ** 2) / sigma ** 2) ** 0.5
+        sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+        derivative = (sample - pred_original) / sigma
+        noise = torch.randn(model_output.shape, dtype=model_output.dtype, device=model_output.device, generator=generator)
+        prev = sample + derivative * (sigma_down - sigma) + noise * sigma_up
+        return {'prev_sample': prev, 'pred_original_sample': pred_original}

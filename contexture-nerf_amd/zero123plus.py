@@ -9,8 +9,13 @@ src/training/trainer.py:296-315); what is built here is the part that sits on th
 
   DepthControlUNet  (:260-298): a ControlNetModel engine whose residuals the UNet adds to its skip tensors / mid output.
 
-Not built: the pipeline __call__ (:748-833) and its schedulers' sampling loop.
+  Zero123PlusPipeline.__call__ / run_sd_pipeline's denoising loop (:411-746, 748-833) over tensors: condition-image latent,
+      CFG pair, EulerAncestral steps (or the explicit one-step schedule of the SDS loop) with `callback_on_step_end` exposing
+      `noise_pred`, unscale_latents -> vae.decode -> unscale_image.  The PIL / CLIP preprocessing and the vision / text encoders are
+      not part of it (no weights offline): `prompt_embeds` / `global_embeds` come in as tensors (seeded stand-ins otherwise); the
+      inpaint / blend extension of run_sd_pipeline (:436-440, 650-708) is not built.
 """
+import types
 import torch
 from . import _lib as L
 from .utils import scale_latents, unscale_latents, scale_image, unscale_image   # noqa: F401  (re-exported like the reference module)
@@ -43,7 +48,7 @@ class RefOnlyNoisedUNet(torch.nn.Module):
         noise = torch.randn_like(cond_lat)
         sched = self.train_sched if self.training else self.val_sched
         t = timestep.reshape(-1) if isinstance(timestep, torch.Tensor) else torch.tensor([timestep])
-        noisy_cond_lat = sched.add_noise(cond_lat, noise, t.to(torch.long).cpu())
+        noisy_cond_lat = sched.add_noise(cond_lat, noise, t.cpu())
         noisy_cond_lat = sched.scale_model_input(noisy_cond_lat, t)
         ref_dict = {}
         self.forward_cond(noisy_cond_lat, float(t[0]), encoder_hidden_states, class_labels, ref_dict, is_cfg_guidance)
@@ -78,3 +83,65 @@ class DepthControlUNet(torch.nn.Module):
         return self.unet(sample, timestep, encoder_hidden_states=encoder_hidden_states,
                          down_block_res_samples=down_block_res_samples, mid_block_res_sample=mid_block_res_sample,
                          cross_attention_kwargs=cross_attention_kwargs)
+
+
+class Zero123PlusPipeline:
+    """Tensor-level mirror of the pipeline's __call__ (src/zero123plus.py:748-833) and of the denoising loop of run_sd_pipeline
+    (:604-746, without the inpaint / blend branch).  unet = DepthControlUNet(RefOnlyNoisedUNet(...)) or RefOnlyNoisedUNet(...)."""
+
+    def __init__(self, vae, unet, scheduler, ramping_coefficients=None):
+        self.vae, self.unet, self.scheduler = vae, unet, scheduler
+        self.ramping_coefficients = ramping_coefficients
+
+    def encode_condition_image(self, image):
+        return self.vae.encode(image).latent_dist.sample()
+
+    @torch.no_grad()
+    def __call__(self, image, prompt_embeds=None, global_embeds=None, guidance_scale=4.0, depth_image=None, output_type="pt",
+                 width=640, height=960, num_inference_steps=28, timesteps=None, latents=None, generator=None,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",)):
+        """image: [1,3,H,W] in [-1,1] (already resized / normalised for the VAE); depth_image: [1,3,height,width] in [0,1];
+        prompt_embeds [1,77,D] (and optionally global_embeds [1,1,D], added with the ramping coefficients as :802-803).
+        -> images [1,3,height,width] in [0,1] (output_type 'pt') or the unscaled latents ('latent')."""
+        dev = image.device
+        inner = self.unet.unet if hasattr(self.unet, 'controlnet') else self.unet
+        cfg = inner.unet.config
+        do_cfg = guidance_scale > 1
+        cond_lat = self.encode_condition_image(image)
+        if do_cfg:
+            cond_lat = torch.cat([self.encode_condition_image(torch.zeros_like(image)), cond_lat])
+        if prompt_embeds is None:
+            g = torch.Generator().manual_seed(0)
+            prompt_embeds = torch.randn(1, 77, cfg['cross_attention_dim'], generator=g).to(dev)
+        if global_embeds is not None:
+            ramp = torch.as_tensor(self.ramping_coefficients if self.ramping_coefficients is not None else [0.0] * prompt_embeds.shape[1],
+                                   dtype=prompt_embeds.dtype, device=dev).unsqueeze(-1)
+            prompt_embeds = prompt_embeds + global_embeds * ramp
+        if do_cfg:                                               # negative prompt embeds first (encode_prompt's ordering)
+            prompt_embeds = torch.cat([torch.zeros_like(prompt_embeds), prompt_embeds])
+        cak = dict(cond_lat=cond_lat)
+        if hasattr(self.unet, 'controlnet'):
+            if depth_image is None:
+                raise L.CtxError("Zero123PlusPipeline: the UNet carries a ControlNet, pass depth_image")
+            cak['control_depth'] = torch.cat([depth_image] * 2) if do_cfg else depth_image
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps, timesteps=timesteps) if timesteps is not None else sch.set_timesteps(num_inference_steps)
+        if latents is None:
+            latents = torch.randn(1, cfg['in_channels'], height // 8, width // 8, generator=generator, device=dev) * sch.init_noise_sigma
+        for i, t in enumerate(sch.timesteps):
+            x = torch.cat([latents] * 2) if do_cfg else latents
+            x = sch.scale_model_input(x, t)
+            noise_pred = self.unet(x, t.reshape(1), prompt_embeds, cross_attention_kwargs=cak)['sample']
+            if do_cfg:
+                nu, nt = noise_pred.chunk(2)
+                noise_pred = nu + guidance_scale * (nt - nu)
+            latents = sch.step(noise_pred, t, latents, generator=generator)['prev_sample']
+            if callback_on_step_end is not None:
+                loc = dict(latents=latents, noise_pred=noise_pred, prompt_embeds=prompt_embeds)
+                out = callback_on_step_end(self, i, t, {k: loc[k] for k in callback_on_step_end_tensor_inputs})
+                latents = out.pop("latents", latents) if isinstance(out, dict) else latents
+        latents = unscale_latents(latents)
+        if output_type == "latent":
+            return types.SimpleNamespace(images=latents)
+        img = unscale_image(self.vae.decode(latents / 0.18215).sample)
+        return types.SimpleNamespace(images=(img / 2 + 0.5).clamp(0, 1))

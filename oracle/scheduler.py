@@ -60,3 +60,32 @@ class PNDMRef:
 def cfg(eps_pair, guidance):
     u, c = eps_pair[0], eps_pair[1]
     return u + np.float32(guidance) * (c - u)
+
+
+class EulerAncestralRef:
+    """numpy restatement of diffusers 0.27.2 EulerAncestralDiscreteScheduler (scaled_linear betas, linspace spacing or an explicit
+    timestep list, epsilon / v prediction).  PARITY UNPINNED (diffusers absent offline): the formulas are the published ones —
+    sigma = sqrt((1-abar)/abar); x_in = x / sqrt(sigma^2+1); x0 = x - sigma*eps  |  x0 = -sigma/sqrt(sigma^2+1) * v + x/(sigma^2+1);
+    sigma_up = sqrt(s_to^2 (s^2 - s_to^2) / s^2); sigma_down = sqrt(s_to^2 - sigma_up^2); x' = x + (x - x0)/s * (sigma_down - s) + n*sigma_up."""
+
+    def __init__(self, T=1000, beta_start=0.00085, beta_end=0.012, prediction_type="v_prediction"):
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=np.float32) ** 2
+        ac = np.cumprod(1.0 - betas)
+        self.sig_all = np.sqrt((1 - ac) / ac).astype(np.float64)
+        self.T, self.prediction_type = T, prediction_type
+
+    def set_timesteps(self, n=None, timesteps=None):
+        ts = np.linspace(0, self.T - 1, n)[::-1].copy() if timesteps is None else np.asarray(timesteps, np.float64)
+        self.timesteps = ts
+        self.sigmas = np.concatenate([np.interp(ts, np.arange(self.T), self.sig_all), [0.0]])
+        return ts
+
+    def scale(self, x, i):
+        return x / np.sqrt(self.sigmas[i] ** 2 + 1)
+
+    def step(self, out, i, x, noise):
+        s, s_to = self.sigmas[i], self.sigmas[i + 1]
+        x0 = x - s * out if self.prediction_type == "epsilon" else out * (-s / np.sqrt(s ** 2 + 1)) + x / (s ** 2 + 1)
+        up = np.sqrt(s_to ** 2 * (s ** 2 - s_to ** 2) / s ** 2)
+        down = np.sqrt(s_to ** 2 - up ** 2)
+        return x + (x - x0) / s * (down - s) + noise * up

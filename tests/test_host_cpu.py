@@ -2,6 +2,7 @@
 config surface, OBJ reader, sample_pdf / ndc_rays host logic) against the reference's own outputs in tests/golden."""
 import os
 import numpy as np
+import pytest
 import torch
 from contexture_nerf_amd import utils as U, views_dataset as VD, config as CFG, kal
 from contexture_nerf_amd import run_nerf_helpers as rnh
@@ -107,6 +108,34 @@ def test_export_format_round_trip(tmp_path):
     i = raw.index(b'IDAT'); n = struct.unpack('>I', raw[i - 4:i])[0]
     px = np.frombuffer(zlib.decompress(raw[i + 4:i + 4 + n]), np.uint8).reshape(7, 1 + 27)[:, 1:].reshape(7, 9, 3)
     assert np.array_equal(px, img)
+
+
+def test_euler_ancestral_scheduler_vs_oracle():
+    """EulerAncestralDiscreteScheduler mirror (torch) vs the oracle's numpy restatement: schedule, input scaling, add_noise, epsilon and
+    v-prediction steps with the same noise, and the explicit one-step schedule of the SDS loop.  (Both restate diffusers 0.27.2:
+    parity unpinned, diffusers is absent offline.)"""
+    from contexture_nerf_amd.scheduler import EulerAncestralDiscreteScheduler
+    from oracle.scheduler import EulerAncestralRef
+    rng = np.random.default_rng(0)
+    for pt in ("v_prediction", "epsilon"):
+        sch = EulerAncestralDiscreteScheduler(prediction_type=pt); ref = EulerAncestralRef(prediction_type=pt)
+        sch.set_timesteps(7); ts = ref.set_timesteps(7)
+        np.testing.assert_allclose(sch.timesteps.numpy(), ts, rtol=1e-6)
+        np.testing.assert_allclose(sch.sigmas.numpy(), ref.sigmas, rtol=1e-5)
+        assert abs(float(sch.init_noise_sigma) - ref.sigmas.max()) < 1e-4
+        x = rng.standard_normal((1, 4, 6, 5)).astype(np.float32); out = rng.standard_normal((1, 4, 6, 5)).astype(np.float32)
+        for i in (0, 3, 6):
+            t = sch.timesteps[i]
+            np.testing.assert_allclose(sch.scale_model_input(torch.tensor(x), t).numpy(), ref.scale(x, i), rtol=1e-5, atol=1e-6)
+            g = torch.Generator().manual_seed(5)
+            nz = torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).numpy()
+            got = sch.step(torch.tensor(out), t, torch.tensor(x), generator=g)['prev_sample'].numpy()
+            np.testing.assert_allclose(got, ref.step(out, i, x, nz), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(sch.add_noise(torch.tensor(x), torch.tensor(out), sch.timesteps[2:3]).numpy(), x + out * ref.sigmas[2], rtol=1e-5, atol=1e-6)
+        sch.set_timesteps(1, timesteps=[515.0]); ref.set_timesteps(timesteps=[515.0])          # one SDS step at a DreamTime t
+        assert sch.timesteps.tolist() == [515.0] and abs(float(sch.sigmas[0]) - ref.sigmas[0]) < 1e-5 and float(sch.sigmas[1]) == 0.0
+        with pytest.raises(ValueError):
+            sch.scale_model_input(torch.tensor(x), 100.0)
 
 
 def test_sampling_host_logic(golden):

@@ -149,3 +149,50 @@ def test_volume_render_and_refine(dev):
     assert float(r['acc'].min()) > 0.5
     d = vr.depth_for_diffusion(r['depth'], r['acc'])
     assert float(d.min()) >= 0.5 and float(d.max()) <= 1.0
+
+
+def test_zero123plus_pipeline_one_step_and_loop(dev):
+    """Tensor-level Zero123++ pipeline on tiny random-init engines: the SDS loop's call shape (one explicit timestep, given noisy
+    latents, noise_pred through callback_on_step_end, src/training/trainer.py:785-795) equals the manual composition of the UNet
+    stack + CFG; a short sampling loop decodes to an image."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel, ControlNetModel
+    from contexture_nerf_amd.vae import AutoencoderKL
+    from contexture_nerf_amd.scheduler import EulerAncestralDiscreteScheduler, DDPMScheduler
+    from contexture_nerf_amd.zero123plus import RefOnlyNoisedUNet, DepthControlUNet, Zero123PlusPipeline, scale_latents
+    from oracle import unet_ref
+    cfg = unet_ref.tiny_config(in_channels=4)
+    net = UNet2DConditionModel(cfg, device=dev, seed=1)
+    cnet = ControlNetModel(cfg, device=dev, seed=2)
+    vae = AutoencoderKL(dict(latent_channels=4, out_channels=3, block_out_channels=(64, 128, 128, 128), layers_per_block=1, groups=32), device=dev, seed=3)
+    sch = EulerAncestralDiscreteScheduler()
+    stack = DepthControlUNet(RefOnlyNoisedUNet(net, DDPMScheduler(), sch).eval(), cnet, conditioning_scale=2.0).eval()
+    pipe = Zero123PlusPipeline(vae, stack, sch)
+    g = torch.Generator().manual_seed(4)
+    image = (torch.rand(1, 3, 64, 64, generator=g) * 2 - 1).to(dev)           # condition image -> 8x8 latent (64 reference tokens)
+    depth = torch.rand(1, 3, 192, 128, generator=g).to(dev)                   # 3x2 depth grid, 8x the 24x16 latent
+    pe = torch.randn(1, 9, cfg['cross_attention_dim'], generator=g).to(dev)
+    z_t = torch.randn(1, 4, 24, 16, generator=g).to(dev)
+    seen = {}
+
+    def cb(p, i, t, kw):
+        seen['noise_pred'] = kw['noise_pred'].clone(); seen['t'] = float(t)
+        return kw
+    torch.manual_seed(11)
+    out = pipe(image, prompt_embeds=pe, depth_image=depth, guidance_scale=10.0, num_inference_steps=1, timesteps=[515.0], latents=z_t,
+               width=128, height=192, output_type='latent', callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents", "noise_pred"])
+    assert seen['t'] == 515.0 and seen['noise_pred'].shape == z_t.shape and torch.isfinite(seen['noise_pred']).all()
+    assert out.images.shape == z_t.shape
+    # manual composition with the same RNG stream (condition-latent samples, then the reference pass's noise draw)
+    torch.manual_seed(11)
+    pos = vae.encode(image).latent_dist.sample()                              # the pipeline encodes the image first, then the zeros
+    cl = torch.cat([vae.encode(torch.zeros_like(image)).latent_dist.sample(), pos])
+    sch.set_timesteps(1, timesteps=[515.0])
+    x = sch.scale_model_input(torch.cat([z_t] * 2), sch.timesteps[0])
+    ctx = torch.cat([torch.zeros_like(pe), pe])
+    v = stack(x, sch.timesteps[0].reshape(1), ctx, cross_attention_kwargs=dict(cond_lat=cl, control_depth=torch.cat([depth] * 2)))['sample']
+    vu, vt = v.chunk(2)
+    assert torch.equal(vu + 10.0 * (vt - vu), seen['noise_pred'])
+    # a short sampling loop to an image
+    img = pipe(image, prompt_embeds=pe, depth_image=depth, guidance_scale=4.0, num_inference_steps=3, width=128, height=192,
+               generator=torch.Generator(device=dev).manual_seed(2)).images
+    assert img.shape == (1, 3, 192, 128) and torch.isfinite(img).all() and float(img.min()) >= 0 and float(img.max()) <= 1
