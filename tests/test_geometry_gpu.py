@@ -456,6 +456,48 @@ def test_field_3d_backward(dev):
     assert all(torch.equal(a, b) for a, b in zip(hw, aw)) and all(torch.equal(a, b) for a, b in zip(hb, ab))
 
 
+def test_texture_field_full_size_properties(dev):
+    """The 1024^2 atlas of the reference (1 048 576 texels) through size-independent properties: the fused grid path
+    equals the explicit-uv path and the float64 oracle on a random subset of texels; the backward is linear in the upstream
+    gradient, and the gradients of two disjoint texel sets add up to the gradient of their union (every texel range of the
+    split-K weight-gradient GEMMs and every tile of the dZ chain contributes exactly once)."""
+    from contexture_nerf_amd import run_nerf_helpers as rnh
+    torch.manual_seed(17)
+    net = rnh.NeRF2D(D=8, W=256, input_ch=42, output_ch=3, skips=[4]).to(dev)
+    res = 1024
+    with torch.no_grad():
+        tex, raw = net.texture_map(res)
+    assert tex.shape == (1, 3, res, res) and torch.isfinite(raw).all()
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randint(0, res * res, (4096,), generator=g)
+    lin = torch.linspace(0, 1, res, device=dev)
+    uv = torch.stack([lin[idx.to(dev) % res], lin[idx.to(dev) // res]], -1)          # (u, v) = (column, row) of the 'xy' meshgrid
+    with torch.no_grad():
+        sub = net.forward_uv(uv)
+    np.testing.assert_allclose(raw[idx.to(dev)].cpu().numpy(), sub.cpu().numpy(), rtol=1e-4, atol=5e-4)
+    ws = [l.weight.detach().cpu().numpy() for l in net.pts_linears]
+    bs = [l.bias.detach().cpu().numpy() for l in net.pts_linears]
+    o = onerf.nerf2d_forward(onerf.embed(uv.cpu().numpy()), ws, bs, net.output_linear.weight.detach().cpu().numpy(),
+                             net.output_linear.bias.detach().cpu().numpy(), dtype=np.float64)
+    np.testing.assert_allclose(sub.cpu().numpy(), o, rtol=1e-3, atol=5e-4)
+    # backward properties at full size
+    gt = torch.randn(1, 3, res, res, generator=g).to(dev)
+    half = (torch.arange(res * res, device=dev) % 7 < 3).reshape(1, 1, res, res).float()          # an irregular split of the texels
+
+    def grads(gtex):
+        net.zero_grad(set_to_none=True)
+        t, _ = net.texture_map(res)
+        t.backward(gtex)
+        return [p.grad.clone() for p in net.parameters()]
+    ga, gb, gab = grads(gt * half), grads(gt * (1 - half)), grads(gt)
+    g2 = grads(2.5 * gt)
+    for a, b, ab, s2 in zip(ga, gb, gab, g2):
+        scale = ab.abs().max().item() + 1e-20
+        assert ((a + b) - ab).abs().max().item() <= 2e-5 * scale           # fp32 partial sums in a different grouping
+        assert (s2 - 2.5 * ab).abs().max().item() <= 2e-5 * scale
+    assert all(torch.equal(x, y) for x, y in zip(gab, grads(gt)))            # deterministic at full size
+
+
 def test_rays_and_composite(dev, golden):
     from contexture_nerf_amd import run_nerf_helpers as rnh
     ro, rd = rnh.get_rays(6, 8, golden['rays_K'], torch.tensor(golden['rays_c2w'], device=dev))

@@ -8,6 +8,7 @@ the oracle's fp16-storage restatement of the reference's autocast contract — a
 that restatement.  north_star's "within 1e-3 rel fp16" is below the noise floor of fp16-operand arithmetic on this
 network: fp16 WEIGHTS alone put any fp16 implementation 0.84e-3 from fp32 (tests/test_precision_cpu.py)."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 import torch
@@ -562,3 +563,25 @@ def test_new_entry_points_fail_loudly(dev):
     with pytest.raises(CtxError):
         with torch.no_grad():
             field.texture_map(16)                                         # the atlas grid is a 2-D input; this field is 3-D
+
+
+def test_unet_full_size_vs_oracle(dev):
+    """BASELINE configs[1] at full size: the SD2-depth UNet (866 M parameters, seeded random init shared through the state_dict),
+    CFG batch 2, latent 96 x 96, 77 context tokens — engine (tuned plans, 256x256 kernel, split-K, fused GroupNorm...) vs the fp32
+    oracle on the host cores (~15 s).  Same gate as the small configurations: rel L2 <= 2.5e-3 (fp16-storage noise floor
+    1.3-1.5e-3, tests/test_precision_cpu.py)."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel
+    from oracle import unet_ref
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    torch.manual_seed(0)
+    ref = unet_ref.randomize_affine(unet_ref.UNet2DConditionModelRef(unet_ref.SD2_DEPTH)).eval()
+    net = UNet2DConditionModel(device=dev, init=False)
+    net.load_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 96, 96, generator=g); ctx = torch.randn(2, 77, 1024, generator=g)
+    with torch.no_grad():
+        want = ref(x, torch.tensor(501.0), ctx)['sample']
+    got = net(x.to(dev), 501.0, ctx.to(dev))['sample']
+    r = _rel(got, want)
+    print(f"full-size UNet (latent 96, batch 2): rel L2 vs fp32 = {r:.3e}")
+    assert torch.isfinite(got).all() and r < 2.5e-3, r
