@@ -123,7 +123,13 @@ class Zero123PlusPipeline:
         if hasattr(self.unet, 'controlnet'):
             if depth_image is None:
                 raise L.CtxError("Zero123PlusPipeline: the UNet carries a ControlNet, pass depth_image")
-            cak['control_depth'] = torch.cat([depth_image] * 2) if do_cfg else depth_image
+            if do_cfg:     # keep the CFG pair of the depth grid across calls: the ControlNet caches its embedding per tensor (identity, version)
+                key = (depth_image.data_ptr(), depth_image._version, tuple(depth_image.shape))
+                if getattr(self, '_depth_key', None) != key:
+                    self._depth_key, self._depth_pair = key, torch.cat([depth_image] * 2)
+                cak['control_depth'] = self._depth_pair
+            else:
+                cak['control_depth'] = depth_image
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps, timesteps=timesteps) if timesteps is not None else sch.set_timesteps(num_inference_steps)
         if latents is None:
