@@ -1,0 +1,56 @@
+"""The denoise side of one iteration of the reference's Zero123++ SDS loop (src/training/trainer.py:700-850), on the HIP
+engines: six rendered views -> 3x2 grid -> scale_image -> VAE encode -> scale_latents -> DDPM noise at the DreamTime t ->
+Zero123++ pipeline, one explicit step, `noise_pred` (a v prediction) through the step-end callback -> v target, Fisher-divergence
+monitor, SDS gradient, `targets = z0 - grad` and the per-tile loss value.
+
+What this does NOT do is backpropagate the loss into the texture: the reference goes through `vae.encode` with autograd, and the VAE
+backward is not built.  Everything up to `targets` — the part that costs the UNet evaluations — is."""
+import random
+import torch
+from .utils import merge_tensor_with_6_elements_to_3x2_grid, split_3x2_grid_to_tensor_with_6_elements, scale_image, scale_latents
+
+VAE_SCALING = 0.18215
+
+
+def views_to_grid(six, tile):
+    """[6,C,t,t] (dataset order, index = 3*col + row as utils.py:326-371) -> [1,C,3t,2t]."""
+    return merge_tensor_with_6_elements_to_3x2_grid(six, tile)
+
+
+@torch.no_grad()
+def sds_iteration_targets(pipe, rendered_six, cond_image, depth_grid, prompt_embeds, t, alphas_cumprod, add_noise,
+                          guidance_scale=10.0, grad_scale=0.2, ikl_running_avg=None, index_to_train=None):
+    """rendered_six [6,3,s,s] in [0,1]; cond_image [1,3,H,W] in [-1,1]; depth_grid [1,3,8h,8w] in [0,1]; t: int timestep;
+    alphas_cumprod: the training scheduler's table (DDPMScheduler); add_noise: its add_noise.
+    -> dict(z0, latents_noisy, v_pred, v, grad, targets, loss, index, ikl_running_avg)."""
+    dev = rendered_six.device
+    tile = rendered_six.shape[-1]
+    grid = views_to_grid(rendered_six, tile)                                          # trainer.py:722-727
+    grid = scale_image(grid * 2 - 1)                                                  # :729-730
+    z0 = pipe.vae.encode(grid).latent_dist.sample() * VAE_SCALING                     # :732-733
+    z0 = scale_latents(z0)                                                            # :735
+    tt = torch.tensor([int(t)])
+    noise = torch.randn_like(z0)                                                      # :742
+    latents_noisy = add_noise(z0, noise, tt)                                          # :746  x_t = sqrt(abar) z0 + sqrt(1-abar) eps
+    seen = {}
+
+    def on_step_end(p, i, ts, kw):                                                    # :774-784
+        seen['v_pred'] = kw['noise_pred']
+        return kw
+    pipe(cond_image, prompt_embeds=prompt_embeds, depth_image=depth_grid, guidance_scale=guidance_scale, num_inference_steps=1,
+         timesteps=[float(t)], latents=latents_noisy, width=grid.shape[-1], height=grid.shape[-2], output_type='latent',
+         callback_on_step_end=on_step_end, callback_on_step_end_tensor_inputs=["latents", "noise_pred"])      # :786-795
+    v_pred = seen['v_pred']
+    ac = alphas_cumprod[int(t)].to(dev)
+    sa, sb = torch.sqrt(ac).reshape(1, 1, 1, 1), torch.sqrt(1.0 - ac).reshape(1, 1, 1, 1)
+    v = sa * noise - sb * z0                                                          # :802
+    fisher = torch.sum((sa.clamp(min=1e-8) / sb.clamp(min=1e-8)) ** 2 * torch.abs(v_pred - v) ** 2).item()   # :817-820
+    ikl_running_avg = fisher if ikl_running_avg is None else 0.99 * ikl_running_avg + 0.01 * fisher             # :823-827
+    grad = torch.nan_to_num(grad_scale * (1.0 - ac) * sa * (v_pred - v))              # :829-834
+    targets = (z0 - grad).float()                                                     # :837
+    lt = z0.shape[-1] // 2
+    zs, ts_ = split_3x2_grid_to_tensor_with_6_elements(z0.float(), lt), split_3x2_grid_to_tensor_with_6_elements(targets, lt)
+    index = random.randint(0, 5) if index_to_train is None else index_to_train       # :842
+    loss = 0.5 * torch.nn.functional.mse_loss(zs[index], ts_[index], reduction='sum') / z0.shape[0]   # :845-854
+    return dict(z0=z0, latents_noisy=latents_noisy, v_pred=v_pred, v=v, grad=grad, targets=targets, loss=loss, index=index,
+                ikl_running_avg=ikl_running_avg)

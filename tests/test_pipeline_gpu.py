@@ -196,3 +196,42 @@ def test_zero123plus_pipeline_one_step_and_loop(dev):
     img = pipe(image, prompt_embeds=pe, depth_image=depth, guidance_scale=4.0, num_inference_steps=3, width=128, height=192,
                generator=torch.Generator(device=dev).manual_seed(2)).images
     assert img.shape == (1, 3, 192, 128) and torch.isfinite(img).all() and float(img.min()) >= 0 and float(img.max()) <= 1
+
+
+def test_sds_iteration_targets(dev):
+    """The denoise side of one SDS iteration (trainer.py:700-850) on tiny engines: shapes, the identities targets = z0 - grad and
+    grad = 0.2 (1 - abar) sqrt(abar) (v_pred - v), loss = 0.5 * |grad tile|^2, the DDPM noising identity, determinism under a seed."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel, ControlNetModel
+    from contexture_nerf_amd.vae import AutoencoderKL
+    from contexture_nerf_amd.scheduler import EulerAncestralDiscreteScheduler, DDPMScheduler
+    from contexture_nerf_amd.zero123plus import RefOnlyNoisedUNet, DepthControlUNet, Zero123PlusPipeline
+    from contexture_nerf_amd.utils import DreamTimeScheduler
+    from contexture_nerf_amd import sds
+    from oracle import unet_ref
+    cfg = unet_ref.tiny_config(in_channels=4)
+    net = UNet2DConditionModel(cfg, device=dev, seed=1); cnet = ControlNetModel(cfg, device=dev, seed=2)
+    vae = AutoencoderKL(dict(latent_channels=4, out_channels=3, block_out_channels=(64, 128, 128, 128), layers_per_block=1, groups=32), device=dev, seed=3)
+    train_sched, val_sched = DDPMScheduler(), EulerAncestralDiscreteScheduler()
+    pipe = Zero123PlusPipeline(vae, DepthControlUNet(RefOnlyNoisedUNet(net, train_sched, val_sched).eval(), cnet, conditioning_scale=2.0).eval(), val_sched)
+    g = torch.Generator().manual_seed(7)
+    six = torch.rand(6, 3, 64, 64, generator=g).to(dev)                       # six rendered views -> 192 x 128 grid -> 24 x 16 latent
+    cond = (torch.rand(1, 3, 64, 64, generator=g) * 2 - 1).to(dev)
+    depth = torch.rand(1, 3, 192, 128, generator=g).to(dev)
+    pe = torch.randn(1, 9, cfg['cross_attention_dim'], generator=g).to(dev)
+    t = int(DreamTimeScheduler(train_sched.alphas_cumprod, 100).get_t(40))
+
+    def run():
+        torch.manual_seed(5)
+        return sds.sds_iteration_targets(pipe, six, cond, depth, pe, t, train_sched.alphas_cumprod, train_sched.add_noise, index_to_train=4)
+    r = run()
+    assert r['z0'].shape == (1, 4, 24, 16) and r['v_pred'].shape == r['z0'].shape and torch.isfinite(r['targets']).all()
+    ac = train_sched.alphas_cumprod[t].item()
+    want_grad = 0.2 * (1 - ac) * ac ** 0.5 * (r['v_pred'] - r['v'])
+    assert torch.allclose(r['grad'], want_grad, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(r['targets'], r['z0'] - r['grad'], rtol=0, atol=1e-6)
+    noise = (r['v'] + (1 - ac) ** 0.5 * r['z0']) / ac ** 0.5                 # invert v = sqrt(abar) eps - sqrt(1-abar) z0
+    assert torch.allclose(r['latents_noisy'], ac ** 0.5 * r['z0'] + (1 - ac) ** 0.5 * noise, rtol=1e-4, atol=1e-5)
+    from contexture_nerf_amd.utils import split_3x2_grid_to_tensor_with_6_elements as split
+    assert abs(r['loss'].item() - 0.5 * split(r['grad'].float(), 8)[4].pow(2).sum().item()) <= 1e-4 * (1 + r['loss'].item())
+    r2 = run()
+    assert torch.equal(r2['v_pred'], r['v_pred']) and torch.equal(r2['targets'], r['targets'])
