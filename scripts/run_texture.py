@@ -24,6 +24,10 @@ def main(cfg: cfgmod.TrainConfig):
     if trainer.rank == 0:
         torch.save({'atlas': atlas.cpu(), 'coverage': coverage.cpu()}, os.path.join(exp, 'atlas.pt'))
         print(f"painted {len(trainer.train_views)} views -> {exp}/atlas.pt  coverage {float((coverage > 0).float().mean()):.3f}")
+    if cfg.log.save_mesh:                               # src/training/trainer.py:962-968: mesh.obj / mesh.mtl / albedo.png
+        out = trainer.export()
+        if out:
+            print(f"mesh written to {out}")
 
 
 if __name__ == '__main__':
