@@ -402,6 +402,23 @@ __global__ __launch_bounds__(256) void k_conv_small(const float *__restrict__ x3
         for (int t = 0; t < 9; ++t) {
             const int iy = oy * stride + t / 3 - 1, ix = ox * stride + t % 3 - 1;
             if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            if (x16 && (Cin & 7) == 0) {         // 16-byte chunks of the pixel's channels against 8 weight chunks (L1-resident)
+                const f16 *xp = x16 + (((int64_t)b * H + iy) * W + ix) * Cin;
+                const f16 *wp = w + ((int64_t)(o8 * 8) * 9 + t) * Cin;
+                for (int c = 0; c < Cin; c += 8) {
+                    const f16x8 xv = *(const f16x8 *)(xp + c);
+                    float xf[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) xf[q] = (float)xv[q];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f16x8 wv = *(const f16x8 *)(wp + (int64_t)j * 9 * Cin + c);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[j] += xf[q] * (float)wv[q];
+                    }
+                }
+                continue;
+            }
             for (int c = 0; c < Cin; ++c) {
                 const float v = x32 ? (float)(f16)x32[(((int64_t)b * Cin + c) * H + iy) * W + ix]
                                     : (float)x16[(((int64_t)b * H + iy) * W + ix) * Cin + c];

@@ -44,9 +44,14 @@ with net.residuals(res):
     y = net.forward_ref(x, 500.0, ctx, 'r', bank=bank, ref_row0=1)[0]['sample']
 e[3].record()
 torch.cuda.synchronize()
+depth2 = depth.clone()                                                     # a new conditioning image: the embedding is recomputed
+e2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+e2[0].record(); cnet(x, 500.0, encoder_hidden_states=ctx, controlnet_cond=depth2, conditioning_scale=2.0); e2[1].record()
+torch.cuda.synchronize()
 fl_main = sum(v[1] for v in net.flops(2, 120, 80, 77).values())          # plain forward; the extra K/V tokens add attention work
 print(json.dumps({"ms_per_iteration": round(dt * 1e3, 3), "iterations_per_s": round(1 / dt, 2),
                   "cond_write_pass_ms": round(e[0].elapsed_time(e[1]), 3), "controlnet_ms": round(e[1].elapsed_time(e[2]), 3),
+                  "controlnet_with_new_depth_image_ms": round(e2[0].elapsed_time(e2[1]), 3),
                   "main_read_pass_ms": round(e[2].elapsed_time(e[3]), 3),
                   "plain_forward_tflop_batch2_120x80": round(fl_main / 1e12, 3), "finite": bool(torch.isfinite(y).all()),
                   "note": "CFG batch 2 on the main and ControlNet passes, batch 1 condition pass"}))
