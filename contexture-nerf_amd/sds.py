@@ -12,6 +12,33 @@ from .utils import merge_tensor_with_6_elements_to_3x2_grid, split_3x2_grid_to_t
 VAE_SCALING = 0.18215
 
 
+def to_rgb_image(rgba):
+    """The reference's to_rgb_image (src/training/trainer.py:533-543) on tensors: an RGBA image [1,4,H,W] in [0,1] is quantised to
+    8 bits (torchvision's to_pil_image: mul(255).byte()) and pasted with its alpha over a grey (127) background, with PIL's
+    rounding ((x*a + 127*(255-a) + 128) folded by (t + (t >> 8)) >> 8; checked against PIL in tests/test_host_cpu.py).  -> [1,3,H,W] uint8-valued float in [0,1]."""
+    q = (rgba.clamp(0, 1) * 255).to(torch.uint8).to(torch.int32)
+    rgb, a = q[:, :3], q[:, 3:4]
+
+    t = rgb * a + 127 * (255 - a) + 128                       # PIL's paste: one rounded division of the blended sum by 255
+    out = (t + (t >> 8)) >> 8
+    return out.clamp(0, 255).float() / 255.0
+
+
+def build_depth_grid(depth_maps, object_masks, size=320):
+    """paint_zero123plus set-up (src/training/trainer.py:575-600): for the six novel views (batch rows 1..6 of the 7-view render)
+    crop depth (3 copies) + mask-as-alpha to the mask's square region, resize to size^2 (bilinear), lay the tiles out 3 x 2
+    (tile index = 3*col + row) and grey the transparent part.  depth_maps, object_masks: [7,1,H,W] -> [1,3,3*size,2*size]."""
+    from .utils import get_nonzero_region_tuple
+    rgba = torch.cat((depth_maps, depth_maps, depth_maps, object_masks), dim=1)
+    tiles = []
+    for i in range(1, depth_maps.shape[0]):
+        min_h, min_w, max_h, max_w = get_nonzero_region_tuple(object_masks[i, 0])
+        tiles.append(torch.nn.functional.interpolate(rgba[i:i + 1, :, min_h:max_h, min_w:max_w], (size, size), mode='bilinear',
+                                                     align_corners=False))
+    grid = merge_tensor_with_6_elements_to_3x2_grid(torch.cat(tiles, 0), size)
+    return to_rgb_image(grid)
+
+
 def views_to_grid(six, tile):
     """[6,C,t,t] (dataset order, index = 3*col + row as utils.py:326-371) -> [1,C,3t,2t]."""
     return merge_tensor_with_6_elements_to_3x2_grid(six, tile)

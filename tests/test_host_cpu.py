@@ -138,6 +138,33 @@ def test_euler_ancestral_scheduler_vs_oracle():
             sch.scale_model_input(torch.tensor(x), 100.0)
 
 
+def test_depth_grid_and_to_rgb_image_vs_pil():
+    """sds.to_rgb_image / build_depth_grid against the reference's formulation run through PIL itself (trainer.py:533-543, 575-600:
+    to_pil_image -> paste over grey 127 with the alpha channel): bit-exact on the 8-bit values."""
+    from PIL import Image
+    from contexture_nerf_amd import sds
+    g = torch.Generator().manual_seed(0)
+    rgba = torch.rand(1, 4, 37, 29, generator=g)
+    rgba[:, 3, :10] = 0.0; rgba[:, 3, 10:20] = 1.0
+    got = (sds.to_rgb_image(rgba)[0] * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()
+    pil = Image.fromarray((rgba[0].mul(255).byte().permute(1, 2, 0).numpy()), 'RGBA')
+    bg = Image.fromarray(np.full((37, 29, 3), 127, np.uint8), 'RGB')
+    bg.paste(pil, mask=pil.getchannel('A'))
+    assert np.array_equal(got, np.asarray(bg))
+    # grid: 7 views, tiles of views 1..6 at positions (row, col) = (k % 3, k // 3)
+    depth = torch.rand(7, 1, 48, 48, generator=g)
+    mask = torch.zeros(7, 1, 48, 48); mask[:, :, 8:40, 12:36] = 1.0
+    grid = sds.build_depth_grid(depth, mask, size=16)
+    assert grid.shape == (1, 3, 48, 32)
+    from contexture_nerf_amd.utils import get_nonzero_region_tuple
+    for k in range(6):
+        h0, w0, h1, w1 = get_nonzero_region_tuple(mask[k + 1, 0])
+        tile = torch.nn.functional.interpolate(torch.cat([depth[k + 1:k + 2]] * 3 + [mask[k + 1:k + 2]], 1)[:, :, h0:h1, w0:w1], (16, 16),
+                                               mode='bilinear', align_corners=False)
+        r, c = k % 3, k // 3
+        assert torch.equal(grid[:, :, 16 * r:16 * r + 16, 16 * c:16 * c + 16], sds.to_rgb_image(tile))
+
+
 def test_sampling_host_logic(golden):
     s = rnh.sample_pdf(torch.tensor(golden['pdf_bins']), torch.tensor(golden['pdf_w']), 24, det=True)
     np.testing.assert_allclose(s.numpy(), golden['pdf_det'], rtol=1e-6, atol=1e-6)
