@@ -5,7 +5,7 @@ O = 'gpurun_out/prof_refresh'
 shutil.copy(f'{O}/r01_bench_default.json', 'profiles/r01_bench_default.json')
 shutil.copy(f'{O}/traffic.json', 'profiles/r01_pmc_traffic.json')
 shutil.copy(f'{O}/r01_bench_by_kernel_and_grid.txt', 'profiles/r01_bench_by_kernel_and_grid.txt')
-for f in ('r01_mesh_bench.json', 'r01_views_in_flight.txt', 'r01_uvmlp_bench.json', 'r01_volume_bench.json'):
+for f in ('r01_mesh_bench.json', 'r01_views_in_flight.txt', 'r01_uvmlp_bench.json', 'r01_volume_bench.json', 'r01_zero123_bench.json', 'r01_sds_iter_bench.json'):
     if os.path.exists(f'{O}/{f}'):
         shutil.copy(f'{O}/{f}', f'profiles/{f}')
 for src, dst in ((f'{O}/r01_geometry_bench.jsonl', 'profiles/r01_geometry_bench.jsonl'), (f'{O}/r01_gemm_layers.txt', 'profiles/r01_gemm_layers.txt')):

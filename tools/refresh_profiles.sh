@@ -20,4 +20,6 @@ timeout -k 10 300 python3 tools/bench_mesh.py 2>/dev/null | tail -1 > $OUT/r01_m
 timeout -k 10 200 python3 tools/bench_concurrent.py 96 10 2>/dev/null | grep view > $OUT/r01_views_in_flight.txt
 timeout -k 10 200 python3 tools/bench_uvmlp.py 1024 5 2>/dev/null | tail -1 > $OUT/r01_uvmlp_bench.json
 timeout -k 10 200 python3 tools/bench_volume.py 512 128 3 2>/dev/null | tail -1 > $OUT/r01_volume_bench.json
+timeout -k 10 200 python3 tools/bench_zero123.py 10 2>/dev/null | tail -1 > $OUT/r01_zero123_bench.json
+timeout -k 10 200 python3 tools/bench_sds_iter.py 10 2>/dev/null | tail -1 > $OUT/r01_sds_iter_bench.json
 ls $OUT
