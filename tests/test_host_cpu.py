@@ -165,6 +165,30 @@ def test_depth_grid_and_to_rgb_image_vs_pil():
         assert torch.equal(grid[:, :, 16 * r:16 * r + 16, 16 * c:16 * c + 16], sds.to_rgb_image(tile))
 
 
+def test_grid_layout_latent_distribution_and_depth_convention():
+    """host pieces of this round: the 3x2 grid layout equals the reference's explicit cat (trainer.py:722-727: rows (0,3), (1,4),
+    (2,5)); DiagonalGaussianDistribution (diffusers 0.27.2 semantics: clamp(logvar,-30,20), mean + std * noise); the ray path's depth
+    convention (foreground 0.5..1 with closer = larger, background 0); contiguous row tiles."""
+    from contexture_nerf_amd import sds, volume_render as vr
+    from contexture_nerf_amd.vae import DiagonalGaussianDistribution
+    g = torch.Generator().manual_seed(0)
+    six = torch.rand(6, 3, 5, 5, generator=g)
+    want = torch.cat((torch.cat((six[0:1], six[3:4]), dim=3), torch.cat((six[1:2], six[4:5]), dim=3), torch.cat((six[2:3], six[5:6]), dim=3)), dim=2)
+    assert torch.equal(sds.views_to_grid(six, 5), want)
+    mom = torch.randn(2, 8, 3, 3, generator=g) * 20
+    d = DiagonalGaussianDistribution(mom)
+    assert float(d.logvar.max()) <= 20 and float(d.logvar.min()) >= -30 and torch.equal(d.mode(), mom[:, :4])
+    s1 = d.sample(generator=torch.Generator().manual_seed(3))
+    n = torch.randn(d.mean.shape, generator=torch.Generator().manual_seed(3))
+    assert torch.allclose(s1, d.mean + torch.exp(0.5 * d.logvar) * n)
+    depth = torch.tensor([[2.0, 1.0], [3.0, 9.0]]); acc = torch.tensor([[0.9, 0.8], [0.7, 0.1]])
+    dm = vr.depth_for_diffusion(depth, acc)
+    assert dm[1, 1] == 0 and dm[0, 1] == 1.0 and dm[1, 0] == 0.5 and abs(float(dm[0, 0]) - 0.75) < 1e-6
+    spans = [vr.shard_rows(13, r, 4) for r in range(4)]
+    assert spans == [(0, 4), (4, 7), (7, 10), (10, 13)]
+    assert vr.pinhole(512, 512)[0, 0] == np.float32(256 / np.tan(np.pi / 6))
+
+
 def test_sampling_host_logic(golden):
     s = rnh.sample_pdf(torch.tensor(golden['pdf_bins']), torch.tensor(golden['pdf_w']), 24, det=True)
     np.testing.assert_allclose(s.numpy(), golden['pdf_det'], rtol=1e-6, atol=1e-6)
