@@ -599,32 +599,54 @@ extern "C" int32_t ctx_conv3x3_f16(const void *x, const void *w, const void *bia
 // Small-M path (time embedding MLP, per-resnet temb projections; M = CFG batch = 2): weight-streaming
 // GEMV, one wave per output feature, 16-byte loads along K, fp32 accumulate.
 //   out[b,n] = act( sum_k x[b,k] * w[n,k] + bias[n] ),  x optionally SiLU'd on load.
+// Two output features per wave and up to GV_U 16-byte chunks per lane per feature, all loaded before the first FMA: the
+// time_emb_proj GEMV streams 52 MB of weights per UNet evaluation and is bound by the bytes it keeps in flight.
+#define GV_U 4
 __global__ __launch_bounds__(256) void k_gemv_f16(const f16 *__restrict__ x, const f16 *__restrict__ w,
                                                   const f16 *__restrict__ bias, int Bm, int N, int K, int silu_in,
                                                   int silu_out, f16 *__restrict__ out)
 {
-    int lane = threadIdx.x & 63;
-    int n = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (n >= N) return;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane * 8; k < K; k += 512) {
-        f16x8 wv = *(const f16x8 *)(w + (size_t)n * K + k);
-        for (int b = 0; b < Bm; ++b) {
-            f16x8 xv = *(const f16x8 *)(x + (size_t)b * K + k);
+    const int lane = threadIdx.x & 63;
+    const int n0 = ((blockIdx.x * 256 + threadIdx.x) >> 6) * 2;
+    if (n0 >= N) return;
+    const int n1 = n0 + 1 < N ? n0 + 1 : n0;
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = 0; k0 < K; k0 += 512 * GV_U) {
+        f16x8 wv[2][GV_U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float xf = (float)xv[j];
-                if (silu_in) xf = xf / (1.0f + __expf(-xf));
-                acc[b] += xf * (float)wv[j];
+        for (int u = 0; u < GV_U; ++u) {
+            const int k = k0 + u * 512 + lane * 8;
+            const int kc = k < K ? k : K - 8;                              // unconditional (clamped) loads, masked below
+            wv[0][u] = *(const f16x8 *)(w + (size_t)n0 * K + kc);
+            wv[1][u] = *(const f16x8 *)(w + (size_t)n1 * K + kc);
+        }
+#pragma unroll
+        for (int u = 0; u < GV_U; ++u) {
+            const int k = k0 + u * 512 + lane * 8;
+            if (k >= K) { wv[0][u] = zero8; wv[1][u] = zero8; }
+            const int kc = k < K ? k : K - 8;
+            for (int b = 0; b < Bm; ++b) {
+                f16x8 xv = *(const f16x8 *)(x + (size_t)b * K + kc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float xf = (float)xv[j];
+                    if (silu_in) xf = xf / (1.0f + __expf(-xf));
+                    acc[0][b] += xf * (float)wv[0][u][j];
+                    acc[1][b] += xf * (float)wv[1][u][j];
+                }
             }
         }
     }
-    for (int b = 0; b < Bm; ++b) {
-        float v = wave_sum(acc[b]);
-        if (lane == 0) {
-            if (bias) v += (float)bias[n];
-            if (silu_out) v = v / (1.0f + __expf(-v));
-            out[(size_t)b * N + n] = (f16)v;
+    for (int r = 0; r < 2; ++r) {
+        const int n = n0 + r;
+        for (int b = 0; b < Bm; ++b) {
+            float v = wave_sum(acc[r][b]);
+            if (lane == 0 && n < N) {
+                if (bias) v += (float)bias[n];
+                if (silu_out) v = v / (1.0f + __expf(-v));
+                out[(size_t)b * N + n] = (f16)v;
+            }
         }
     }
 }
@@ -632,11 +654,11 @@ __global__ __launch_bounds__(256) void k_gemv_f16(const f16 *__restrict__ x, con
 int ctx_gemv_f16(const f16 *x, const f16 *w, const f16 *bias, int Bm, int N, int K, int silu_in, int silu_out, f16 *out,
                  hipStream_t s)
 {
-    if (Bm > 4 || K % 8 != 0) {
+    if (Bm > 4 || K % 8 != 0 || K < 8) {
         ctx_set_error("gemv: Bm=%d (<=4) K=%d (%%8)", Bm, K);
         return CTX_E_ARG;
     }
-    hipLaunchKernelGGL(k_gemv_f16, dim3(cdiv(N, 4)), dim3(256), 0, s, x, w, bias, Bm, N, K, silu_in, silu_out, out);
+    hipLaunchKernelGGL(k_gemv_f16, dim3(cdiv(N, 8)), dim3(256), 0, s, x, w, bias, Bm, N, K, silu_in, silu_out, out);
     return CTX_OK;
 }
 

@@ -613,9 +613,9 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
     f16 *te1 = u->allocH((size_t)B * u->temb_dim);
     note(u, 2, 2.0 * B * ch[0] * u->temb_dim); RUN(ctx_gemv_f16(te0, u->W + u->t1w, u->W + u->t1b, B, u->temb_dim, ch[0], 0, 1, te1, u->s));
     f16 *te2 = u->allocH((size_t)B * u->temb_dim);
-    note(u, 2, 2.0 * B * u->temb_dim * u->temb_dim); RUN(ctx_gemv_f16(te1, u->W + u->t2w, u->W + u->t2b, B, u->temb_dim, u->temb_dim, 0, 0, te2, u->s));
+    note(u, 2, 2.0 * B * u->temb_dim * u->temb_dim); RUN(ctx_gemv_f16(te1, u->W + u->t2w, u->W + u->t2b, B, u->temb_dim, u->temb_dim, 0, 1, te2, u->s));   // + the resnets' SiLU(temb), once
     f16 *tproj = u->allocH((size_t)B * u->temb_rows);
-    note(u, 2, 2.0 * B * u->temb_rows * u->temb_dim); RUN(ctx_gemv_f16(te2, u->W + u->tpw, u->W + u->tpb, B, u->temb_rows, u->temb_dim, 1, 0, tproj, u->s));
+    note(u, 2, 2.0 * B * u->temb_rows * u->temb_dim); RUN(ctx_gemv_f16(te2, u->W + u->tpw, u->W + u->tpb, B, u->temb_rows, u->temb_dim, 0, 0, tproj, u->s));
     f.tproj = tproj;
     f16 *ctx16 = u->allocH((size_t)B * L * c.cross_attention_dim);
     note(u, 2, 0); RUN(ctx_f32_to_f16(ctx, (int64_t)B * L * c.cross_attention_dim, ctx16, u->s));
