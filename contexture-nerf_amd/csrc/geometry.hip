@@ -627,8 +627,8 @@ __global__ __launch_bounds__(256) void k_vw_mark(const int64_t *__restrict__ fac
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < HW; i += (int64_t)gridDim.x * 512) {
         int64_t f0 = p[i];
         int64_t f1 = (i + 1 < HW) ? p[i + 1] : -1;
-        if (f0 >= 0) vis[(size_t)b * F + f0] = 1;
-        if (f1 >= 0) vis[(size_t)b * F + f1] = 1;
+        if (f0 >= 0 && f0 < F) vis[(size_t)b * F + f0] = 1;      // a face id outside [0, F) must not become a stray store
+        if (f1 >= 0 && f1 < F) vis[(size_t)b * F + f1] = 1;
     }
 }
 
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void k_vw_mask(const int64_t *__restrict__ fac
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
         int64_t f = p[i];
         uint8_t m = 1;
-        if (f >= 0) m = !(fnz[(size_t)b * F + f] < max_z[f]);
+        if (f >= 0 && f < F) m = !(fnz[(size_t)b * F + f] < max_z[f]);
         o[i] = m;
     }
 }

@@ -115,13 +115,72 @@ class PNDMScheduler:
 
 
 class DDPMScheduler:
-    """add_noise-only subset used on the reference's SDS path (src/training/trainer.py:746)."""
-    def __init__(self, beta_start=0.00085, beta_end=0.012, num_train_timesteps=1000, **kw):
-        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    """diffusers 0.27.2 DDPMScheduler, the subset the reference's Zero123++ path uses: `add_noise` (src/training/trainer.py:746)
+    and, because `init_zero123plus` swaps it in as the PIPELINE's scheduler (`DDPMScheduler.from_config(pipeline.scheduler.config)`,
+    trainer.py:306), `set_timesteps(timesteps=[t])`, the identity `scale_model_input`, `init_noise_sigma == 1` and the ancestral
+    `step` (variance_type "fixed_small", no sample clipping) for epsilon / v prediction.  Host-side tensor arithmetic.
+    PARITY UNPINNED vs diffusers (absent offline)."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, beta_start=0.00085, beta_end=0.012, num_train_timesteps=1000, beta_schedule="scaled_linear",
+                 prediction_type="v_prediction", **kw):
+        if beta_schedule == "scaled_linear":
+            self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise ValueError(f"DDPMScheduler: beta_schedule {beta_schedule!r} not implemented")
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.num_train_timesteps = num_train_timesteps
+        self.prediction_type = prediction_type
+        self.timesteps = torch.arange(num_train_timesteps - 1, -1, -1)
+        self.custom_timesteps = False
+        self.num_inference_steps = None
 
     add_noise = PNDMScheduler.add_noise
     scale_model_input = PNDMScheduler.scale_model_input
+
+    def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None):
+        if timesteps is not None:
+            ts = [int(round(float(t))) for t in timesteps]
+            if any(ts[i] <= ts[i + 1] for i in range(len(ts) - 1)):
+                raise ValueError("`custom_timesteps` must be in descending order.")
+            if ts[0] >= self.num_train_timesteps:
+                raise ValueError(f"`timesteps` must start before `self.config.train_timesteps`: {self.num_train_timesteps}.")
+            self.timesteps, self.custom_timesteps = torch.tensor(ts, dtype=torch.int64), True
+            self.num_inference_steps = len(ts)
+        else:
+            ratio = self.num_train_timesteps // num_inference_steps             # timestep_spacing "leading", steps_offset 0
+            self.timesteps = torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64))
+            self.custom_timesteps, self.num_inference_steps = False, num_inference_steps
+
+    def previous_timestep(self, t):
+        if self.custom_timesteps:
+            idx = (self.timesteps == int(t)).nonzero()[0][0].item()
+            return -1 if idx == len(self.timesteps) - 1 else int(self.timesteps[idx + 1])
+        n = self.num_inference_steps if self.num_inference_steps else self.num_train_timesteps
+        return int(t) - self.num_train_timesteps // n
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+        t = int(round(float(timestep.reshape(-1)[0]))) if isinstance(timestep, torch.Tensor) else int(round(float(timestep)))
+        prev_t = self.previous_timestep(t)
+        ac = self.alphas_cumprod
+        a_t = float(ac[t]); a_prev = float(ac[prev_t]) if prev_t >= 0 else 1.0
+        b_t, b_prev = 1.0 - a_t, 1.0 - a_prev
+        cur_a = a_t / a_prev; cur_b = 1.0 - cur_a
+        if self.prediction_type == "epsilon":
+            x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+        elif self.prediction_type == "v_prediction":
+            x0 = a_t ** 0.5 * sample - b_t ** 0.5 * model_output
+        else:
+            raise ValueError(f"DDPMScheduler: prediction_type {self.prediction_type!r}")
+        prev = (a_prev ** 0.5 * cur_b / b_t) * x0 + (cur_a ** 0.5 * b_prev / b_t) * sample
+        if t > 0:
+            var = max(b_prev / b_t * cur_b, 1e-20)                                # fixed_small
+            noise = torch.randn(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
+            prev = prev + var ** 0.5 * noise
+        return {'prev_sample': prev, 'pred_original_sample': x0}
 
 
 class EulerAncestralDiscreteScheduler:

@@ -4,13 +4,14 @@
 
 Offline facts: no SD2 weights / tokenizer / diffusers => the UNet is the SD2-depth ARCHITECTURE with
 seeded random-init weights (or a local safetensors state_dict passed as `unet_state_dict`), text embeddings come
-from a caller-supplied encoder or are seeded random [2,77,1024]; the VAE decoder is the HIP engine of vae.py
-(AutoencoderKL architecture, random-init offline or a local state_dict); the VAE encoder is not built (its output
-is discarded on the reference's live path).
+from a caller-supplied encoder or are seeded random [2,77,1024] (seed = a stable SHA-256 digest of the prompt, the
+same in every process); the VAE encoder and decoder are the HIP engine of vae.py (AutoencoderKL architecture,
+random-init offline or a local state_dict / safetensors file).
 
 Additions over the reference: `image_size` is a parameter (the reference hard-wires 512, :519) because
 BASELINE.json's configs run 256^2 / 512^2 / 768^2.
 """
+import hashlib
 import torch
 import torch.nn.functional as F
 from . import _lib as L
@@ -48,7 +49,12 @@ class StableDiffusion:
         """-> cat([uncond, cond]) [2,77,1024].  With no encoder (offline) a seeded random embedding stands in."""
         if self.text_encoder is not None:
             return self.text_encoder(prompt, negative_prompt)
-        g = torch.Generator().manual_seed(hash((tuple(prompt), seed)) % (2 ** 31))
+        # stable digest, not hash(): str hashing is randomised per interpreter, and every rank / run must condition its
+        # views on the same embedding for the same prompt
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        neg = [] if negative_prompt is None else ([negative_prompt] if isinstance(negative_prompt, str) else list(negative_prompt))
+        key = '\0'.join(prompt) + '\1' + '\0'.join(neg) + '\1' + str(int(seed))
+        g = torch.Generator().manual_seed(int.from_bytes(hashlib.sha256(key.encode('utf-8')).digest()[:4], 'little') & 0x7fffffff)
         return torch.randn(2, 77, self.unet.config['cross_attention_dim'], generator=g).to(self.device)
 
     def get_timesteps(self, num_inference_steps, strength):

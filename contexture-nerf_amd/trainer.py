@@ -38,12 +38,19 @@ class ConTEXTure:
         self.view_weights = None
         self.back_im = torch.full((3, 64, 64), 0.5, device=self.device)
 
+    def _offset_phi(self, phi):
+        """phi - front_offset, wrapped into [0, 2 pi) (trainer.py:378-380, 974-976): ONE helper for define_view_weights and
+        paint_viewpoint, so that view-weight masks and painted views always share their cameras."""
+        phi = float(phi) - math.radians(self.cfg.render.front_offset)
+        return float(phi + 2 * math.pi if phi < 0 else phi)
+
     # ---- trainer.py:370-415 ----------------------------------------------------------------------------------
     def define_view_weights(self, view_ids=None):
         """Weight masks for the (local shard of) views; with >1 ranks the per-face maxima are all-reduced (MAX)."""
         ids = list(range(len(self.train_views))) if view_ids is None else list(view_ids)
         thetas = torch.tensor([self.train_views[i]['theta'] for i in ids], device=self.device)
-        phis = torch.tensor([self.train_views[i]['phi'] for i in ids], device=self.device)
+        # same front_offset shift and wrap as paint_viewpoint (trainer.py:378-380): the masks must come from the painted cameras
+        phis = torch.tensor([self._offset_phi(self.train_views[i]['phi']) for i in ids], device=self.device)
         radii = torch.tensor([float(self.train_views[i]['radius']) for i in ids], device=self.device)
         B = len(ids)
         mm = self.mesh_model
@@ -63,8 +70,7 @@ class ConTEXTure:
     def _paint_prepare(self, data, image_size=None, num_inference_steps=None):
         """Everything of paint_viewpoint up to the diffusion call: render, crop box; returns (img2img kwargs, context)."""
         theta, phi, radius = data['theta'], data['phi'], data['radius']
-        phi = phi - math.radians(self.cfg.render.front_offset)
-        phi = float(phi + 2 * math.pi if phi < 0 else phi)
+        phi = self._offset_phi(phi)
         G = self.cfg.render.train_grid_size
         background = F.interpolate(self.back_im.unsqueeze(0), (G, G), mode='bilinear', align_corners=False) \
             if not self.cfg.guide.use_background_color else torch.tensor([0.0, 0.8, 0.0], device=self.device)

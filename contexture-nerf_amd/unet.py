@@ -319,18 +319,3 @@ class ControlNetModel(UNet2DConditionModel):
             out.append(half[off:off + B * hh * ww * cc].view(B, hh, ww, cc)); off += B * hh * ww * cc
         return out, out[-1]
 
-
-def smoke_check(dev):
-    """One tiny denoise evaluation against the fp32 oracle (called from __graft_entry__.smoke)."""
-    from oracle import unet_ref
-    cfg = unet_ref.tiny_config()
-    torch.manual_seed(0)
-    ref = unet_ref.randomize_affine(unet_ref.UNet2DConditionModelRef(cfg)).eval()
-    net = UNet2DConditionModel(cfg, device=dev, init=False)
-    net.load_state_dict(ref.state_dict())
-    x = torch.randn(2, 5, 16, 16); ctx = torch.randn(2, 7, cfg['cross_attention_dim'])
-    with torch.no_grad():
-        want = ref(x, torch.tensor(481.0), ctx)['sample']
-    got = net(x.to(dev), 481.0, ctx.to(dev))['sample'].cpu()
-    rel = (got - want).norm() / want.norm()
-    assert rel < 5e-3, f"UNet smoke: relative error {rel:.3e}"

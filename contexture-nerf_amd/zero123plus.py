@@ -132,8 +132,12 @@ class Zero123PlusPipeline:
                 cak['control_depth'] = depth_image
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps, timesteps=timesteps) if timesteps is not None else sch.set_timesteps(num_inference_steps)
+        # diffusers 0.27.2 `prepare_latents` (spec: src/zero123plus.py:612-623) multiplies by init_noise_sigma whether it drew the
+        # latents or the caller supplied them (the SDS loop passes latents=latents_noisy; 1.0 under the reference's DDPMScheduler,
+        # sqrt(sigma_max^2 + 1) under the pipeline's stock EulerAncestral scheduler)
         if latents is None:
-            latents = torch.randn(1, cfg['in_channels'], height // 8, width // 8, generator=generator, device=dev) * sch.init_noise_sigma
+            latents = torch.randn(1, cfg['in_channels'], height // 8, width // 8, generator=generator, device=dev)
+        latents = latents * sch.init_noise_sigma
         for i, t in enumerate(sch.timesteps):
             x = torch.cat([latents] * 2) if do_cfg else latents
             x = sch.scale_model_input(x, t)

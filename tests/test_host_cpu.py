@@ -197,3 +197,94 @@ def test_sampling_host_logic(golden):
     no, nd = rnh.ndc_rays(6, 8, 5.0, 1.0, torch.tensor(golden['rays_o']), torch.tensor(golden['rays_d']))
     np.testing.assert_allclose(no.numpy(), golden['ndc_o'], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(nd.numpy(), golden['ndc_d'], rtol=1e-6, atol=1e-6)
+
+
+def test_product_camera_path_vs_oracle_and_geometry():
+    """The PRODUCT's camera chain — Renderer.get_camera_from_multiple_view / get_camera_from_view ->
+    kal.generate_transformation_matrix, kal.generate_perspective_projection (src/models/render.py:8-46) — fed with theta / phi / r
+    of the 7 Zero123++ and 10 Multiview poses, against oracle/geometry.py's restatement AND against what a look-at camera must
+    do whatever the formulas are (eye -> origin, look-at point -> -z axis at the eye distance, world up stays in the +y half
+    plane, orthonormal right-handed rotation): a sign or axis slip in either restatement fails the second half."""
+    from contexture_nerf_amd.render import Renderer
+    from oracle import geometry as og
+    rc = CFG.RenderConfig()
+    dy = 0.25
+    for cls in (VD.Zero123PlusDataset, VD.MultiviewDataset):
+        views = list(cls(rc, 'cpu'))
+        assert len(views) in (7, 10)
+        th = torch.tensor([float(v['theta']) for v in views]); ph = torch.tensor([float(v['phi']) for v in views])
+        r = torch.tensor([float(v['radius']) for v in views])
+        M = Renderer.get_camera_from_multiple_view(th, ph, r, look_at_height=dy)                      # [B,4,3]
+        want = og.get_camera_from_multiple_view(th.numpy(), ph.numpy(), r.numpy(), dy)
+        assert M.shape == (len(views), 4, 3)
+        np.testing.assert_allclose(M.numpy(), want, rtol=0, atol=2e-6)
+        for k in range(len(views)):                                                                   # single-view twin
+            M1 = Renderer.get_camera_from_view(th[k], ph[k], r=r[k], look_at_height=0.0)
+            w1 = og.get_camera_from_multiple_view(th[k:k + 1].numpy(), ph[k:k + 1].numpy(), r[k:k + 1].numpy(), 0.0)
+            np.testing.assert_allclose(M1.numpy(), w1, rtol=0, atol=2e-6)
+        R, t = M[:, :3, :].double(), M[:, 3, :].double()
+        eye = torch.stack([r * torch.sin(th) * torch.sin(ph), r * torch.cos(th), r * torch.sin(th) * torch.cos(ph)], 1).double()
+        look = torch.zeros_like(eye); look[:, 1] = dy
+        to_cam = lambda p: torch.einsum('bi,bij->bj', p, R) + t                                       # [v,1] @ M as kaolin applies it
+        assert to_cam(eye).abs().max() < 1e-5
+        lc = to_cam(look)
+        dist = (eye - look).norm(dim=1)
+        assert lc[:, :2].abs().max() < 1e-5 and torch.allclose(lc[:, 2], -dist, atol=1e-5)            # camera looks down -z
+        upc = to_cam(eye + torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64))
+        assert (upc[:, 1] > 0).all() and upc[:, 0].abs().max() < 1e-5                                 # world up -> image up, no roll
+        eye3 = torch.eye(3, dtype=torch.float64).expand(len(views), 3, 3)
+        assert (R.transpose(1, 2) @ R - eye3).abs().max() < 1e-5 and torch.allclose(torch.linalg.det(R), torch.ones(len(views), dtype=torch.float64), atol=1e-5)
+    P = kal.render.camera.generate_perspective_projection(np.pi / 3)
+    assert P.shape == (3, 1) and P.dtype == torch.float32
+    np.testing.assert_array_equal(P.numpy(), og.generate_perspective_projection(np.pi / 3))
+    np.testing.assert_allclose(P[:, 0].numpy(), [1 / np.tan(np.pi / 6), 1 / np.tan(np.pi / 6), -1.0], rtol=1e-6)
+    assert Renderer('cpu', dim=(8, 8)).camera_projection.shape == (3, 1)
+
+
+def test_text_embedding_seed_is_stable_across_interpreters():
+    """The stand-in text embedding must be the same in every process (ranks under torchrun, reruns): its seed comes from a
+    SHA-256 digest of the prompt, not from hash() (str hashing is randomised per interpreter)."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import hashlib, inspect\n"
+            "from contexture_nerf_amd import stable_diffusion_depth as S\n"
+            "src = inspect.getsource(S.StableDiffusion.get_text_embeds)\n"
+            "assert 'hash((' not in src and 'sha256' in src\n"
+            "import torch, types\n"
+            "sd = S.StableDiffusion.__new__(S.StableDiffusion); sd.text_encoder = None; sd.device = 'cpu'\n"
+            "sd.unet = types.SimpleNamespace(config={'cross_attention_dim': 32})\n"
+            "z = sd.get_text_embeds(['a photo of a nascar, front view'])\n"
+            "print(hashlib.sha256(z.numpy().tobytes()).hexdigest())\n") % ROOT
+    outs = []
+    for seed in ('1', '2'):
+        env = dict(os.environ, PYTHONHASHSEED=seed)
+        outs.append(subprocess.check_output([sys.executable, '-c', code], env=env).decode().strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 64
+
+
+def test_ddpm_scheduler_step_identities():
+    """DDPMScheduler mirror (the pipeline scheduler the reference swaps in, trainer.py:306): one explicit timestep as the SDS loop
+    calls it; with the TRUE v (or epsilon) as model output the step's pred_original_sample is x0; init_noise_sigma is 1; the
+    final step (prev_t < 0) returns x0 itself."""
+    from contexture_nerf_amd.scheduler import DDPMScheduler
+    g = torch.Generator().manual_seed(0)
+    x0, eps = torch.randn(1, 4, 6, 4, generator=g), torch.randn(1, 4, 6, 4, generator=g)
+    for pt in ("v_prediction", "epsilon"):
+        sch = DDPMScheduler(prediction_type=pt)
+        assert sch.init_noise_sigma == 1.0
+        sch.set_timesteps(1, timesteps=[515.0])
+        assert sch.timesteps.tolist() == [515] and sch.previous_timestep(515) == -1
+        t = torch.tensor([515])
+        ac = float(sch.alphas_cumprod[515])
+        xt = sch.add_noise(x0, eps, t)
+        assert torch.allclose(xt, ac ** 0.5 * x0 + (1 - ac) ** 0.5 * eps, atol=1e-6)
+        out = ac ** 0.5 * eps - (1 - ac) ** 0.5 * x0 if pt == "v_prediction" else eps
+        assert torch.equal(sch.scale_model_input(xt, t), xt)
+        r = sch.step(out, t, xt, generator=torch.Generator().manual_seed(1))
+        assert torch.allclose(r['pred_original_sample'], x0, atol=2e-5)
+        sch.set_timesteps(1, timesteps=[0.0])
+        r0 = sch.step(eps if pt == "epsilon" else float(sch.alphas_cumprod[0]) ** 0.5 * eps - (1 - float(sch.alphas_cumprod[0])) ** 0.5 * x0,
+                      torch.tensor([0]), sch.add_noise(x0, eps, torch.tensor([0])))
+        assert torch.allclose(r0['prev_sample'], x0, atol=2e-4)
+    with pytest.raises(ValueError):
+        DDPMScheduler().set_timesteps(2, timesteps=[10.0, 20.0])

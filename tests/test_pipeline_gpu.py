@@ -187,7 +187,9 @@ def test_zero123plus_pipeline_one_step_and_loop(dev):
     pos = vae.encode(image).latent_dist.sample()                              # the pipeline encodes the image first, then the zeros
     cl = torch.cat([vae.encode(torch.zeros_like(image)).latent_dist.sample(), pos])
     sch.set_timesteps(1, timesteps=[515.0])
-    x = sch.scale_model_input(torch.cat([z_t] * 2), sch.timesteps[0])
+    # caller-supplied latents are multiplied by init_noise_sigma too (diffusers prepare_latents), then scaled for the model
+    assert float(sch.init_noise_sigma) > 1.0
+    x = sch.scale_model_input(torch.cat([z_t * sch.init_noise_sigma] * 2), sch.timesteps[0])
     ctx = torch.cat([torch.zeros_like(pe), pe])
     v = stack(x, sch.timesteps[0].reshape(1), ctx, cross_attention_kwargs=dict(cond_lat=cl, control_depth=torch.cat([depth] * 2)))['sample']
     vu, vt = v.chunk(2)
