@@ -13,6 +13,8 @@ random-init weights and synthetic text/depth inputs (no network for checkpoints 
 
 N>1: one process per GPU; the 6-8 views of a mesh shard one per rank (weak scaling: every rank denoises its
 own view, no data-path collective inside the denoise loop); value = total steps of all ranks / max time.
+The line also carries `sec_per_mesh`: ONE measured ConTEXTure.paint (6 views over the job's ranks, both
+all-reduces inside).  `--mode mesh` makes that the timed quantity (a step = one mesh; strong scaling).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -39,7 +41,56 @@ def parse():
     p.add_argument("--cpu-latent", type=int, default=0, help="latent side of the CPU sample (0 = auto)")
     p.add_argument("--vae", type=int, default=1, help="also time the once-per-view VAE decode (outside the step loop)")
     p.add_argument("--two-views", type=int, default=1, help="also measure 2 views in flight on one GPU (outside the timed region)")
+    p.add_argument("--mode", choices=("steps", "mesh"), default="steps",
+                   help="steps: UNet denoise steps/s (the driver's line).  mesh: a step is one whole ConTEXTure.paint of a 6-view mesh "
+                        "(views sharded over the ranks, both all-reduces inside): measured sec/mesh, strong scaling")
+    p.add_argument("--mesh", type=int, default=1, help="steps mode: also MEASURE sec/mesh with one ConTEXTure.paint (outside the timed region)")
+    p.add_argument("--mesh-path", default="shapes/nascar.obj")
+    p.add_argument("--mesh-views", type=int, default=6)
+    p.add_argument("--in-flight", type=int, default=3, help="views a rank keeps in its denoise loop at once (optim.views_in_flight)")
     return p.parse_args()
+
+
+def make_painter(a, dev, unet):
+    """ConTEXTure over the bench's UNet engine: bundled mesh, Zero123PlusDataset views 1..6, 1200^2 render, latent a.latent,
+    50 PLMS steps, VAE decode, view weights, UV scatter, atlas merge (BASELINE metric, first half: sec/mesh)."""
+    from contexture_nerf_amd import config as CFG
+    from contexture_nerf_amd.trainer import ConTEXTure
+    from contexture_nerf_amd.stable_diffusion_depth import StableDiffusion
+    cfg = CFG.TrainConfig()
+    cfg.guide.text = "a photo of a car"
+    cfg.guide.shape_path = a.mesh_path
+    cfg.guide.guidance_scale = a.guidance
+    cfg.guide.sd_image_size = a.latent * 8
+    cfg.guide.num_inference_steps = 50
+    cfg.optim.views_in_flight = a.in_flight
+    sd = StableDiffusion(dev, unet=unet)
+    tr = ConTEXTure(cfg, device=dev, diffusion=sd)
+    tr.train_views = tr.train_views[1:1 + a.mesh_views]
+    tr.text_z = sd.get_text_embeds([cfg.guide.text])
+    return tr
+
+
+def timed_paints(tr, n, warm, dist, dev):
+    """n ConTEXTure.paint calls bracketed by barrier + synchronize; -> max-over-ranks seconds, atlas coverage."""
+    for _ in range(warm):
+        tr.paint()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        atlas, cov = tr.paint()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    assert torch.isfinite(atlas).all()
+    return el, float((cov > 0).float().mean())
 
 
 def cpu_baseline(latent, budget_s=60.0, forced=0):
@@ -124,6 +175,24 @@ def main():
             state["lat"] = sched.step_cfg(eps, a.guidance, t, lat)['prev_sample']   # K15+K16 fused
             state["i"] += 1
         return step, state
+
+    if a.mode == "mesh":
+        # strong scaling: ONE mesh, its views sharded over the ranks, measured wall time per mesh
+        tr = make_painter(a, dev, unet)
+        el, cover = timed_paints(tr, a.steps, max(1, a.warmup), dist, dev)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "sec/mesh full texture (6 views, 50 PLMS steps)", "value": round(el / a.steps, 4), "unit": "s/mesh",
+                "n_gpus": world, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": round(el / a.steps * 1e3, 2),
+                "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[2]/[1] shapes: {a.mesh_path}, {a.mesh_views} views (Zero123PlusDataset 1..{a.mesh_views}) "
+                                       f"@1200^2 render, SD2-depth fp16 at latent {S}^2, 50 PLMS steps (51 UNet evals) per view, VAE decode, "
+                                       "view weights + UV scatter, all-reduce(MAX) [F] + all-reduce(SUM) [4,1024,1024]; random-init weights",
+                           "views": a.mesh_views, "views_in_flight": a.in_flight, "parallelism": f"view-shard x{world}"},
+                "atlas_coverage": round(cover, 4)}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     step, state = make_view(unet, 1234 + rank)               # each rank = its own view
 
@@ -210,15 +279,29 @@ def main():
         dist.all_reduce(atlas); torch.cuda.synchronize()
         atlas_ms = (time.perf_counter() - t1) * 1e3
 
+    # measured sec/mesh (BASELINE metric, first half): one whole ConTEXTure.paint over this job's ranks, outside the timed region
+    mesh_s, mesh_cover = None, None
+    if a.mesh:
+        try:
+            tr = make_painter(a, dev, unet)
+            mesh_s, mesh_cover = timed_paints(tr, 1, 1, dist, dev)
+            del tr
+        except Exception as e:                              # never lose the steps/s line to the mesh leg
+            mesh_s, mesh_cover = None, f"failed: {e}"
+            if dist is not None:
+                raise
+
     # HBM-side bytes per launch of the dominant kernel family: PMC counters cannot be collected from inside this process,
     # so the figure is the committed result of tools/pmc_traffic.sh (same command line, same workload) when present
     traffic, traffic_src = None, None
-    tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tf):
+    import glob
+    tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))      # newest round's PMC pass
+    tf = tfs[-1] if tfs else ""
+    if tf:
         try:
             tj = json.load(open(tf))
             traffic = round(tj["families"]["gemm_conv"]["bytes_per_launch"])
-            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per GEMM/conv launch)"
+            traffic_src = f"profiles/{os.path.basename(tf)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, per GEMM/conv launch)"
         except Exception:
             traffic = None
     if rank == 0:
@@ -245,6 +328,10 @@ def main():
             "attention": {"kernel": "k_attention_dma", "achieved": round(fl["attention"][1] / (att_ms * 1e-3) / 1e12, 2) if att_ms > 0 else 0.0,
                           "unit": "TFLOP/s", "launches_per_step": att_n, "kernel_ms_per_step": round(att_ms, 3)},
         }
+        out["sec_per_mesh"] = round(mesh_s, 3) if mesh_s is not None else None
+        out["sec_per_mesh_note"] = (f"MEASURED: one ConTEXTure.paint of {a.mesh_path}, {a.mesh_views} views over {world} rank(s), "
+                                    f"{a.in_flight} views in flight per rank, 1200^2 render, 51 UNet evals + VAE decode per view, "
+                                    f"view weights, UV scatter, atlas merge; coverage {mesh_cover}")
         if two is not None:
             out["views_in_flight"] = two
             out["sec_per_mesh_6_views_est_2_in_flight"] = round(-(-6 // world) * (51 * two["2"]["ms_per_step_per_view"] + (vae_ms or 0.0)) / 1e3, 3)

@@ -3,9 +3,9 @@
 `paint_viewpoint` :971-1117, plus the per-view loop north_star describes (views sharded one per GPU,
 UV back-projection as a scatter into the atlas, RCCL all-reduce of the atlas).
 
-Not built: the 5000-iteration Zero123++ SDS loop (`paint_zero123plus`), eval/video/mesh export,
-wandb/loguru logging.  `project_back` has no body in the reference (trainer.py:1079-1089 calls an undefined
-method); `project_back_scatter` below is the direct UV-scatter form (parity unpinned, documented in DESIGN.md).
+Also here: `project_back` under the reference's call contract (trainer.py:1076-1090; it has no body there, so the
+direct UV-scatter form `project_back_scatter` stands in, parity unpinned), the eval renders (`eval_render`,
+`evaluate`, `full_eval`, :913-968, 1119-1157) and the mesh export.  Not built: wandb/loguru logging, the mp4 mux.
 """
 import math
 import torch
@@ -48,6 +48,16 @@ class ConTEXTure:
     def define_view_weights(self, view_ids=None):
         """Weight masks for the (local shard of) views; with >1 ranks the per-face maxima are all-reduced (MAX)."""
         ids = list(range(len(self.train_views))) if view_ids is None else list(view_ids)
+        group = self.group if self.world > 1 else None
+        if self.world > 1 and group is None:
+            import torch.distributed as dist
+            group = dist.group.WORLD
+        self._vw_ids = ids
+        if not ids:                                     # a rank without views of this mesh still joins the all-reduce(MAX)
+            F_ = self.mesh_model.mesh.faces.shape[0]
+            D.all_reduce_max_(torch.full((F_,), float('-inf'), device=self.device), group)
+            self.view_weights = None
+            return None
         thetas = torch.tensor([self.train_views[i]['theta'] for i in ids], device=self.device)
         # same front_offset shift and wrap as paint_viewpoint (trainer.py:378-380): the masks must come from the painted cameras
         phis = torch.tensor([self._offset_phi(self.train_views[i]['phi']) for i in ids], device=self.device)
@@ -57,10 +67,6 @@ class ConTEXTure:
         mask, depth, normals_image, face_normals, face_idx = mm.render_face_normals_face_idx(
             mm.mesh.vertices[None].repeat(B, 1, 1), mm.mesh.faces, mm.face_attributes, elev=thetas, azim=phis, radius=radii,
             look_at_height=mm.dy)
-        group = self.group if self.world > 1 else None
-        if self.world > 1 and group is None:
-            import torch.distributed as dist
-            group = dist.group.WORLD
         self.view_weights = view_weights.view_weight_masks(face_idx, face_normals, group=group)
         self._vw_cache = dict(mask=mask, depth=depth, face_idx=face_idx, face_normals=face_normals)
         return self.view_weights
@@ -90,7 +96,7 @@ class ConTEXTure:
                   fixed_seed=self.cfg.optim.seed, intermediate_vis=False,
                   num_inference_steps=num_inference_steps or self.cfg.guide.num_inference_steps,
                   image_size=image_size or self.cfg.guide.sd_image_size)
-        ctx = dict(render_cache=render_cache, z_normals=z_normals, rgb_render=rgb_render, object_mask=object_mask,
+        ctx = dict(render_cache=render_cache, z_normals=z_normals, rgb_render=rgb_render, object_mask=object_mask, background=background,
                    box=(min_h, min_w, max_h, max_w), crop_hw=(cropped_rgb_render.shape[2], cropped_rgb_render.shape[3]))
         return kw, ctx
 
@@ -103,11 +109,19 @@ class ConTEXTure:
         self._last = dict(render_cache=ctx['render_cache'], z_normals=ctx['z_normals'])
         return rgb_output, ctx['object_mask']
 
-    def paint_viewpoint(self, data, should_project_back=False, image_size=None, num_inference_steps=None):
+    def paint_viewpoint(self, data, should_project_back=True, image_size=None, num_inference_steps=None):
+        """trainer.py:971-1117.  With should_project_back (the reference's default) the painted view goes into the running atlas
+        through `project_back` with the reference's argument list (:1076-1090; z_normals are withheld under use_zero123plus as
+        there); the fitted render is kept in `self.fitted_pred_rgb`."""
         kw, ctx = self._paint_prepare(data, image_size, num_inference_steps)
         te = kw.pop('text_embeddings'); inp = kw.pop('inputs'); dm = kw.pop('original_depth_mask')
         cropped_rgb_output, _ = self.diffusion.img2img_step(te, inp, dm, **kw)
-        return self._paint_finish(ctx, cropped_rgb_output)
+        rgb_output, object_mask = self._paint_finish(ctx, cropped_rgb_output)
+        if should_project_back:
+            z = None if self.cfg.guide.use_zero123plus else ctx['z_normals']
+            self.fitted_pred_rgb = self.project_back(render_cache=ctx['render_cache'], background=ctx['background'], rgb_output=rgb_output,
+                                                     object_mask=object_mask, update_mask=object_mask, z_normals=z, z_normals_cache=None)
+        return rgb_output, object_mask
 
     def paint_viewpoints_multi(self, datas, image_size=None, num_inference_steps=None):
         """Several views painted with their denoise loops in flight together (StableDiffusion.img2img_step_multi): same result
@@ -139,17 +153,105 @@ class ConTEXTure:
                                             L.ptr(face_idx.contiguous(), torch.int64), L.ptr(contrib), L.stream()))
         return contrib
 
+    @torch.no_grad()
+    def project_back(self, render_cache, background, rgb_output, object_mask, update_mask, z_normals=None, z_normals_cache=None):
+        """The call the reference makes at trainer.py:1076-1090 (its body is missing there; upstream TEXTure fits the
+        texture image to `rgb_output` under `update_mask` by Adam): here the painted pixels are scattered straight into the
+        running atlas contribution `self.atlas_contrib` [3+1,T,T] with weight = update_mask * object_mask (* z_normals when given:
+        the view-facing weight TEXTure's masks are built from; * the view-weight mask of this view when `define_view_weights` ran
+        for it), then the view is re-rendered from the normalised atlas.  `z_normals_cache` is accepted for the call contract and
+        not read (there is no meta-texture in this build).  -> fitted_pred_rgb [B,3,H,W].  PARITY UNPINNED (no reference body)."""
+        from . import kal
+        T = self.cfg.guide.texture_resolution
+        w = (update_mask > 0).float() * (object_mask > 0).float()
+        if z_normals is not None:
+            w = w * z_normals.clamp(0, 1)
+        contrib = self.project_back_scatter(render_cache, rgb_output, w)
+        if getattr(self, 'atlas_contrib', None) is None:
+            self.atlas_contrib = torch.zeros(4, T, T, device=self.device)
+        self.atlas_contrib += contrib
+        wsum = self.atlas_contrib[3:]
+        atlas = (self.atlas_contrib[:3] / wsum.clamp_min(1e-8))[None]
+        uv, face_idx = render_cache['uv_features'], render_cache['face_idx']
+        feat = kal.render.mesh.texture_mapping(uv, atlas.expand(uv.shape[0], -1, -1, -1).contiguous(), mode='bilinear', mask_idx=face_idx)
+        cov = kal.render.mesh.texture_mapping(uv, (wsum > 0).float()[None].expand(uv.shape[0], -1, -1, -1).contiguous(), mode='nearest',
+                                              mask_idx=face_idx)
+        feat, cov = feat.permute(0, 3, 1, 2), cov.permute(0, 3, 1, 2)
+        mask = (object_mask > 0).float() * (cov > 0).float()
+        bg = background.reshape(1, 3, 1, 1) if background.dim() == 1 else background
+        return (bg * (1 - mask) + feat * mask).clamp(0, 1)
+
+    # ---- trainer.py:913-968, 1119-1157 ------------------------------------------------------------------------
+    @torch.no_grad()
+    def eval_render(self, data):
+        """-> (rgb_render [1,H,W,3], texture_rgb [1,T,T,3], depth_render [1,H,W,1], pred_z_normals [1,1,H,W]).  As the reference:
+        white background at cfg.render.eval_grid_size, pixels still at the default colour shaded grey by their z-normal.  The
+        reference reads `pred_z_normals` from a meta-texture render; without a meta texture it is this view's own z-normal."""
+        phi = self._offset_phi(data['phi'])
+        dim = self.cfg.render.eval_grid_size
+        mm = self.mesh_model
+        outputs = mm.render(theta=data['theta'], phi=phi, radius=data['radius'], dims=(dim, dim), background='white')
+        z_normals = outputs['normals'][:, -1:, :, :].clamp(0, 1)
+        rgb_render = outputs['image']
+        default = torch.tensor(getattr(mm, 'default_color', [0.8, 0.1, 0.8]), device=self.device).view(1, 3, 1, 1)
+        uncolored = ((rgb_render - default).abs().sum(dim=1) < 0.1).float().unsqueeze(0)
+        shade = torch.tensor([0.85, 0.85, 0.85], device=self.device).view(1, 3, 1, 1) * (0.3 + 0.7 * z_normals)      # utils.color_with_shade
+        rgb_render = rgb_render * (1 - uncolored) + shade * uncolored
+        atlas = getattr(self, 'atlas', None)
+        tex = outputs['texture_map'] if atlas is None else self._painted_texture(outputs['texture_map'])
+        return (rgb_render.permute(0, 2, 3, 1).contiguous().clamp(0, 1), tex.permute(0, 2, 3, 1).contiguous().clamp(0, 1),
+                outputs['depth'].permute(0, 2, 3, 1).contiguous(), z_normals)
+
+    def _painted_texture(self, base):
+        cov = (self.atlas_coverage > 0)[None, None].to(base.dtype)
+        return base * (1 - cov) + self.atlas[None, :3] * cov
+
+    @torch.no_grad()
+    def evaluate(self, dataloader, save_path, save_as_video=False):
+        """trainer.py:913-952: one rgb frame (+ normal map) per eval view and the texture atlas, under the reference's file names.
+        `save_as_video`: the reference muxes an mp4 with imageio (absent offline); the frames are written as numbered JPGs."""
+        import os
+        import numpy as np
+        from PIL import Image
+        save_path = str(save_path)
+        os.makedirs(save_path, exist_ok=True)
+        to8 = lambda t: (t.detach().cpu().numpy() * 255).astype(np.uint8)
+        n, textures = 0, None
+        for i, data in enumerate(dataloader):
+            preds, textures, depths, normals = self.eval_render(data)
+            tag = 'video_frame' if save_as_video else 'rendered_image'
+            Image.fromarray(to8(preds[0])).save(os.path.join(save_path, f"eval:{tag}:{i:04d}_rgb.jpg"))
+            if not save_as_video:
+                nm = to8(normals[0, 0])
+                Image.fromarray(np.stack([nm, nm, nm], -1)).save(os.path.join(save_path, f"eval:normal_map:{i:04d}_normals_cache.jpg"))
+                if self.paint_step == 0:
+                    torch.save(depths[0].cpu(), os.path.join(save_path, f"eval:depth_map:{i:04d}_depth.pt"))
+            n += 1
+        if textures is not None:
+            Image.fromarray(to8(textures[0])).save(os.path.join(save_path, "eval:texture_atlas:texture.png"))
+        return n
+
+    def full_eval(self, output_dir=None, size=None):
+        """trainer.py:954-968: the `val_large` orbit (cfg.log.full_eval_size views) + mesh export (rank 0 only)."""
+        from .views_dataset import ViewsDataset
+        if D.dist.is_initialized() and D.dist.get_rank(self.group) != 0:
+            return None
+        out = self.cfg.log.exp_dir / 'results' if output_dir is None else output_dir
+        n = self.evaluate(ViewsDataset(self.cfg.render, self.device, size=size or self.cfg.log.full_eval_size), out, save_as_video=True)
+        if self.cfg.log.save_mesh:
+            if getattr(self, 'atlas', None) is not None:
+                self.export(str(self.cfg.log.exp_dir / 'mesh') if output_dir is None else str(output_dir) + '/mesh')
+            else:
+                self.mesh_model.export_mesh(str(self.cfg.log.exp_dir / 'mesh') if output_dir is None else str(output_dir) + '/mesh')
+        return n
+
     def paint(self, image_size=None, num_inference_steps=None):
         """Per-view paint loop with views sharded one per rank and one atlas all-reduce at the end."""
         n = len(self.train_views)
         mine = D.shard_views(n, self.rank, self.world)
         T = self.cfg.guide.texture_resolution
         contrib = torch.zeros(4, T, T, device=self.device)
-        if mine:
-            masks = self.define_view_weights(mine)
-        else:                                           # idle rank still joins the collectives
-            F_ = self.mesh_model.mesh.faces.shape[0]
-            D.all_reduce_max_(torch.full((F_,), float('-inf'), device=self.device), self.group)
+        masks = self.define_view_weights(mine)          # an idle rank (no views of this mesh) still joins the all-reduce(MAX)
         # a rank that owns several views keeps `views_in_flight` of them (default 3) in the denoise loop at once
         infl = max(1, int(getattr(self.cfg.optim, 'views_in_flight', 3)))
         if not hasattr(self.diffusion, 'img2img_step_multi'):
@@ -163,7 +265,8 @@ class ConTEXTure:
                 for o, (rgb, obj_mask, last) in enumerate(res):
                     contrib += self.project_back_scatter(last['render_cache'], rgb, masks[j + o:j + o + 1] & (obj_mask > 0))
             else:
-                rgb, obj_mask = self.paint_viewpoint(self.train_views[grp[0]], image_size=image_size, num_inference_steps=num_inference_steps)
+                rgb, obj_mask = self.paint_viewpoint(self.train_views[grp[0]], should_project_back=False, image_size=image_size,
+                                                     num_inference_steps=num_inference_steps)
                 contrib += self.project_back_scatter(self._last['render_cache'], rgb, masks[j:j + 1] & (obj_mask > 0))
             j += len(grp)
         atlas, coverage = D.merge_atlas(contrib, self.group)

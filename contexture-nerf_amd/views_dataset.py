@@ -64,3 +64,18 @@ class MultiviewDataset(_PoseList):
         for phi, theta in cfg.views_after:
             self.phis, self.thetas = self.phis + [phi], self.thetas + [theta]
         self.size = len(self.phis)
+
+
+class ViewsDataset(_PoseList):
+    """Evaluation orbit (src/training/views_dataset.py:220-260, the non-random branch): `size` views on a circle at
+    radius 1.2 x cfg.radius, theta = cfg.base_theta, phi = index / size * 360 degrees."""
+    def __init__(self, cfg, device, size=100, random_views=False):
+        if random_views:
+            raise NotImplementedError("ViewsDataset(random_views=True): rand_poses is unused on the paint / eval path (SURVEY section 2)")
+        self.cfg, self.device, self.size, self.random_views = cfg, device, size, False
+
+    def collate(self, index):
+        phi = (index[0] / self.size) * 360
+        dirs, thetas, phis, radius = circle_poses(self.device, radius=self.cfg.radius * 1.2, theta=self.cfg.base_theta, phi=phi,
+                                                  angle_overhead=self.cfg.overhead_range, angle_front=self.cfg.front_range)
+        return {'dir': dirs, 'theta': thetas, 'phi': phis, 'radius': radius, 'base_theta': math.radians(self.cfg.base_theta)}
