@@ -440,11 +440,12 @@ def forward_fp16_storage(model, sample, timestep, ctx, q=_h, q_res=_h, q_w=_h):
         return {'sample': mq.conv_out(q(F.silu(mq.conv_norm_out(hh))))}
 
 
-def ref_only_forward(model, sample, timestep, ctx, noisy_cond_lat, is_cfg_guidance):
+def ref_only_forward(model, sample, timestep, ctx, noisy_cond_lat, is_cfg_guidance, down_res=None, mid_res=None):
     """RefOnlyNoisedUNet.forward of src/zero123plus.py:164-237 on the fp32 oracle UNet (the condition latent arrives already
     noised: the noise draw and the scheduler are the caller's): 'w' pass over the condition parks each attn1's input
     (with is_cfg_guidance only the conditional context row is used), 'r' pass appends them along the token axis to the K/V
-    source of the same attn1, the unconditional batch row 0 attending without them."""
+    source of the same attn1, the unconditional batch row 0 attending without them.  down_res / mid_res: ControlNet residuals
+    injected into the 'r' pass."""
     blocks = [m for m in model.modules() if isinstance(m, BasicTransformerBlock)]
     st = {'mode': 'w', 'bank': {}, 'row0': 0}
     for b in blocks:
@@ -452,7 +453,11 @@ def ref_only_forward(model, sample, timestep, ctx, noisy_cond_lat, is_cfg_guidan
     try:
         model(noisy_cond_lat, timestep, ctx[1:] if is_cfg_guidance else ctx)
         st['mode'] = 'r'; st['row0'] = 1 if is_cfg_guidance else 0
-        out = model(sample, timestep, ctx)
+        # ControlNet residuals go to the main ('r') pass only (DepthControlUNet -> RefOnlyNoisedUNet.forward, spec :205-237, 260-298)
+        if down_res is not None:
+            out = model(sample, timestep, ctx, down_block_additional_residuals=down_res, mid_block_additional_residual=mid_res)
+        else:
+            out = model(sample, timestep, ctx)
     finally:
         for b in blocks:
             del b._ref_state

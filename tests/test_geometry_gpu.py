@@ -519,3 +519,78 @@ def test_rays_and_composite(dev, golden):
         # tolerance: wave-parallel prefix product / sums vs sequential float32 oracle, expf ulp differences
         for a, b in zip(out, o):
             np.testing.assert_allclose(a.cpu().numpy(), b, rtol=2e-4, atol=2e-6)
+
+
+def test_volume_render_full_size_vs_oracle(dev):
+    """BASELINE configs[4] at FULL size: 512^2 rays x 128 samples through the 3-D field NeRF2D(D 8, W 256, input_ch 63, output_ch 4)
+    and raw2outputs on the HIP path (33.5 M field evaluations, one launch chain), checked (a) against the float64 numpy oracle
+    field + the C compositing oracle on a subset of image rows (top, centre, bottom: 3 x 512 rays x 128 samples), (b) through the
+    size-independent property that a row-tile render equals the same rows of the whole-image render bit for bit (rays are
+    independent: the multi-GPU row sharding of SURVEY section 8e).  Parity unpinned vs a reference run (no ray-march body upstream)."""
+    from contexture_nerf_amd import run_nerf_helpers as rnh, volume_render as vr
+    H = W_ = 512
+    S = 128
+    torch.manual_seed(77)
+    field = rnh.NeRF2D(D=8, W=256, input_ch=63, output_ch=4, skips=[4]).to(dev)
+    with torch.no_grad():
+        field.output_linear.bias[3] = 1.0                       # some density, so that weights / acc are not ~0 everywhere
+    c2w = torch.tensor([[1, 0, 0, 0.05], [0, 1, 0, -0.02], [0, 0, 1, 1.5]], dtype=torch.float32, device=dev)
+    K = vr.pinhole(H, W_)
+    full = vr.render_image(field, H, W_, K, c2w, 0.5, 2.5, S)
+    assert full['rgb'].shape == (H, W_, 3) and all(torch.isfinite(v).all() for v in full.values())
+    rows = (0, 255, 511)
+    ro, rd = rnh.get_rays(H, W_, K, c2w)
+    t = torch.linspace(0., 1., S, device=dev)
+    ws = [l.weight.detach().cpu().numpy() for l in field.pts_linears]
+    bs = [l.bias.detach().cpu().numpy() for l in field.pts_linears]
+    wo, bo = field.output_linear.weight.detach().cpu().numpy(), field.output_linear.bias.detach().cpu().numpy()
+    for r in rows:
+        o, d = ro[r].reshape(-1, 3), rd[r].reshape(-1, 3)
+        z = (0.5 * (1 - t) + 2.5 * t).expand(W_, S).contiguous()
+        pts = (o[:, None, :] + d[:, None, :] * z[:, :, None]).reshape(-1, 3).cpu().numpy()
+        raw = onerf.nerf2d_forward(onerf.embed(pts), ws, bs, wo, bo, dtype=np.float64).reshape(W_, S, 4)
+        want = og.raw2outputs(raw.astype(np.float32), z.cpu().numpy(), d.cpu().numpy(), white_bkgd=False)
+        tile = vr.render_image(field, H, W_, K, c2w, 0.5, 2.5, S, rows=(r, r + 1))
+        for k in ('rgb', 'depth', 'acc', 'disp'):
+            assert torch.equal(tile[k][0], full[k][r]), (k, r)                     # (b)
+        # (a): the fp32 embedding of |x| 2^9 ~ 1e3 arguments differs from the float64 one by ~1e-4 (as at the small size);
+        # after compositing over 128 samples the image-level quantities agree to ~1e-3
+        np.testing.assert_allclose(full['rgb'][r].cpu().numpy(), want[0], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(full['acc'][r].cpu().numpy(), want[2], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(full['depth'][r].cpu().numpy(), want[4], rtol=2e-3, atol=4e-3)
+    tiles = [vr.render_image(field, H, W_, K, c2w, 0.5, 2.5, S, rows=vr.shard_rows(H, k, 8)) for k in (0, 3, 7)]
+    for k, tl in zip((0, 3, 7), tiles):
+        r0, r1 = vr.shard_rows(H, k, 8)
+        assert torch.equal(tl['rgb'], full['rgb'][r0:r1]) and torch.equal(tl['depth'], full['depth'][r0:r1])
+
+
+def test_project_back_scatter_vs_oracle(dev, meshes):
+    """The UV back-projection scatter of ConTEXTure.project_back_scatter (C = 3 colours + weight, face-index mask) == the C
+    oracle's texture_mapping backward (`orc_texture_mapping_bwd`, the restatement of grid_sample's backward) on the same pixels:
+    a real raster of a bundled mesh at 600^2 into a 256^2 atlas, with a half-empty weight mask."""
+    from contexture_nerf_amd import kal
+    from contexture_nerf_amd.trainer import ConTEXTure
+    v = og.normalize_mesh(meshes["spot_triangulated_v"], 0.6, 0.25); f = meshes["spot_triangulated_f"].astype(np.int64)
+    vt, ft = meshes["spot_triangulated_vt"], meshes["spot_triangulated_ft"].astype(np.int64)
+    B, Hh, Ww, T = 2, 600, 600, 256
+    cam = og.get_camera_from_multiple_view(np.float32([1.0471976, 1.9198622]), np.float32([0.5, 3.6]), np.float32([1.5, 1.5]), 0.25)
+    proj = og.generate_perspective_projection(np.pi / 3)
+    g_cam, g_img, g_fn = kal.render.mesh.prepare_vertices(torch.tensor(np.repeat(v[None], B, 0), device=dev), torch.tensor(f, device=dev),
+                                                          torch.tensor(proj), camera_transform=torch.tensor(cam, device=dev))
+    uv_attr = torch.tensor(vt[ft][None].repeat(B, 0), device=dev)
+    depth, uv, face_idx, normals = kal.render.mesh.rasterize_fused(Hh, Ww, g_cam, g_img, uv_attr, g_fn)
+    rng = np.random.default_rng(3)
+    rgb = torch.tensor(rng.random((B, 3, Hh, Ww), dtype=np.float32), device=dev)
+    wmask = torch.tensor(rng.random((B, 1, Hh, Ww)) > 0.5, device=dev)
+    tr = ConTEXTure.__new__(ConTEXTure)
+    tr.cfg = type('C', (), {'guide': type('G', (), {'texture_resolution': T})()})()
+    contrib = tr.project_back_scatter(dict(uv_features=uv, face_idx=face_idx), rgb, wmask)
+    assert contrib.shape == (4, T, T)
+    w = wmask.float().permute(0, 2, 3, 1)
+    go = torch.cat([rgb.permute(0, 2, 3, 1) * w, w], -1).cpu().numpy()
+    go = go * (face_idx.cpu().numpy() >= 0)[..., None]                                # the kernel's face-index mask
+    want = og.texture_mapping_bwd(go, uv.cpu().numpy(), T)
+    want = want.sum(0) if want.ndim == 4 else want
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(contrib.cpu().numpy(), want, rtol=0, atol=2e-5 * max(scale, 1.0))      # float atomics: order-dependent sums
+    assert float(contrib[3].sum()) > 1000

@@ -585,3 +585,43 @@ def test_unet_full_size_vs_oracle(dev):
     r = _rel(got, want)
     print(f"full-size UNet (latent 96, batch 2): rel L2 vs fp32 = {r:.3e}")
     assert torch.isfinite(got).all() and r < 2.5e-3, r
+
+
+def test_zero123pp_full_size_vs_oracle(dev):
+    """BASELINE configs[2] at FULL size: the Zero123++-shaped denoise evaluation — SD2-family UNet (in_channels 4, 320/640/1280/1280),
+    CFG batch 2 on the 3x2 view grid latent [2,4,120,80], the noised 40x40 condition latent parked by the 'w' pass (1 600 reference
+    tokens appended to the level-0 self-attention K/V of the conditional row; 400 / 100 at the deeper levels), depth ControlNet
+    over the 960x640 grid with conditioning scale 2 and its 13 residuals injected into the 'r' pass — against the fp32 oracle's
+    restatement of src/zero123plus.py:127-298 on the host cores.  Gate as at the small sizes (2.5e-3; fp16 floor 1.3-1.5e-3)."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel, ControlNetModel
+    from oracle import unet_ref
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    cfg = dict(unet_ref.SD2_DEPTH, in_channels=4)
+    torch.manual_seed(3)
+    ref = unet_ref.randomize_affine(unet_ref.UNet2DConditionModelRef(cfg)).eval()
+    cref = unet_ref.randomize_affine(unet_ref.ControlNetModelRef(cfg), seed=1).eval()
+    net = UNet2DConditionModel(cfg, device=dev, init=False); net.load_state_dict(ref.state_dict())
+    cnet = ControlNetModel(cfg, device=dev, init=False); cnet.load_state_dict(cref.state_dict())
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 120, 80, generator=g)
+    cond = 2 * torch.randn(1, 4, 40, 40, generator=g)
+    ctx = torch.randn(2, 77, 1024, generator=g)
+    depth = torch.rand(1, 3, 960, 640, generator=g).expand(2, -1, -1, -1).contiguous()
+    t = 515.0
+    with torch.no_grad():
+        wd, wm = cref(x, torch.tensor(t), ctx, depth, conditioning_scale=2.0)
+        want = unet_ref.ref_only_forward(ref, x, torch.tensor(t), ctx, cond, True, down_res=wd, mid_res=wm)['sample']
+    res, mid = cnet(x.to(dev), t, encoder_hidden_states=ctx.to(dev), controlnet_cond=depth.to(dev), conditioning_scale=2.0)
+    for k, w in enumerate(wd + [wm]):
+        rk = _rel(res[k].float().permute(0, 3, 1, 2) * 2.0, w)
+        assert rk < 3e-3, (k, rk)
+    _, bank = net.forward_ref(cond.to(dev), t, ctx[1:].to(dev), 'w')
+    with net.residuals(res):
+        got = net.forward_ref(x.to(dev), t, ctx.to(dev), 'r', bank=bank, ref_row0=1)[0]['sample']
+    r = _rel(got, want)
+    with net.residuals(res):
+        no_ref = net(x.to(dev), t, encoder_hidden_states=ctx.to(dev))['sample']
+    print(f"full-size Zero123++ evaluation (latent 120x80, 1600 ref tokens, ControlNet): rel L2 vs fp32 = {r:.3e}; "
+          f"without the reference tokens {_rel(no_ref, want):.3e}")
+    assert torch.isfinite(got).all() and r < 2.5e-3, r
+    assert _rel(no_ref, want) > 4 * r
