@@ -12,6 +12,7 @@ Additions over the reference: `image_size` is a parameter (the reference hard-wi
 BASELINE.json's configs run 256^2 / 512^2 / 768^2.
 """
 import hashlib
+import os
 import torch
 import torch.nn.functional as F
 from . import _lib as L
@@ -36,10 +37,24 @@ class StableDiffusion:
         self.num_train_timesteps = 1000
         self.min_step = int(self.num_train_timesteps * min_timestep)
         self.max_step = int(self.num_train_timesteps * max_timestep)
-        self.unet = unet if unet is not None else UNet2DConditionModel(device=device, seed=seed, init=unet_state_dict is None)
+        # `model_name` may be a LOCAL directory in the diffusers layout (unet/diffusion_pytorch_model.safetensors,
+        # vae/diffusion_pytorch_model.safetensors): the files are read by safetensors_io (nothing is fetched by name offline)
+        local = model_name if isinstance(model_name, str) and os.path.isdir(model_name) else None
+        unet_file = os.path.join(local, 'unet', 'diffusion_pytorch_model.safetensors') if local else None
+        vae_file = os.path.join(local, 'vae', 'diffusion_pytorch_model.safetensors') if local else None
+        from_file = unet is None and unet_state_dict is None and unet_file is not None and os.path.exists(unet_file)
+        self.unet = unet if unet is not None else UNet2DConditionModel(device=device, seed=seed,
+                                                                       init=unet_state_dict is None and not from_file)
         if unet_state_dict is not None:
             self.unet.load_state_dict(unet_state_dict)
-        self.vae = vae if vae is not None else AutoencoderKL(device=device, seed=seed)      # decoder engine (random-init offline)
+        elif from_file:
+            self.unet.load_file(unet_file)
+        if vae is not None:
+            self.vae = vae
+        elif vae_file is not None and os.path.exists(vae_file):
+            self.vae = AutoencoderKL.from_file(vae_file, device=device)
+        else:
+            self.vae = AutoencoderKL(device=device, seed=seed)      # random-init offline
         self.text_encoder = text_encoder
         self.scheduler = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                                        num_train_timesteps=self.num_train_timesteps, steps_offset=1, skip_prk_steps=True)

@@ -117,6 +117,19 @@ class UNet2DConditionModel:
         torch.cuda.synchronize(self.device)   # sources must outlive the async repack kernels
         return missing, extra
 
+    def load_file(self, path, strict=True):
+        """Weights from a local safetensors file with diffusers' parameter names (what `from_pretrained` would have fetched by
+        model name, src/stable_diffusion_depth.py:58-88); fp16 / bf16 / fp32 payloads are accepted and repacked to the engine's
+        fp16 layout.  The file is memory-mapped: tensors go to the device one at a time."""
+        from .safetensors_io import load_file
+        return self.load_state_dict(load_file(path), strict=strict)
+
+    @classmethod
+    def from_file(cls, path, config=None, device="cuda:0", strict=True):
+        net = cls(config, device=device, init=False)
+        net.load_file(path, strict=strict)
+        return net
+
     def init_random(self, seed=0):
         """torch default initialisers (kaiming_uniform(a=sqrt 5) => U(-1/sqrt(fan_in), +)), norms = (1, 0)."""
         g = torch.Generator(device=self.device).manual_seed(seed)

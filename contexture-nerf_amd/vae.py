@@ -82,6 +82,17 @@ class AutoencoderKL:
         torch.cuda.synchronize(self.device)
         return missing
 
+    def load_file(self, path, strict=True):
+        """Weights from a local safetensors file with diffusers' AutoencoderKL names (memory-mapped, any float dtype)."""
+        from .safetensors_io import load_file
+        return self.load_state_dict(load_file(path), strict=strict)
+
+    @classmethod
+    def from_file(cls, path, config=None, device="cuda:0", strict=True):
+        vae = cls(config, device=device, init=False)
+        vae.load_file(path, strict=strict)
+        return vae
+
     def init_random(self, seed=0):
         g = torch.Generator(device=self.device).manual_seed(seed)
         fan = {n[:-7]: math.prod(s[1:]) for n, s in zip(self._names, self._shapes) if n.endswith('.weight') and len(s) >= 2}

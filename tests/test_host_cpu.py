@@ -288,3 +288,46 @@ def test_ddpm_scheduler_step_identities():
         assert torch.allclose(r0['prev_sample'], x0, atol=2e-4)
     with pytest.raises(ValueError):
         DDPMScheduler().set_timesteps(2, timesteps=[10.0, 20.0])
+
+
+def test_safetensors_reader_writer(tmp_path):
+    """contexture_nerf_amd.safetensors_io: round trip on a file this test writes (fp32 / fp16 / bf16 / int64, a 0-d and an empty
+    tensor), agreement with the `safetensors` package in both directions where it is importable, and loud failures on a
+    truncated file, an oversized header, offsets that do not match the shape, and a non-JSON header."""
+    import json, struct
+    from contexture_nerf_amd import safetensors_io as sio
+    g = torch.Generator().manual_seed(0)
+    sd = {"conv_in.weight": torch.randn(8, 5, 3, 3, generator=g), "b.half": torch.randn(7, generator=g).half(),
+          "c.bf16": torch.randn(3, 2, generator=g).bfloat16(), "d.idx": torch.arange(6).reshape(2, 3), "e.scalar": torch.tensor(2.5),
+          "f.empty": torch.zeros(0, 4)}
+    path = str(tmp_path / "m.safetensors")
+    sio.save_file(sd, path, metadata={"format": "pt"})
+    hdr, meta, off = sio.read_header(path)
+    assert set(hdr) == set(sd) and meta == {"format": "pt"} and off % 8 == 0
+    got = sio.load_file(path)
+    for k, v in sd.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and torch.equal(got[k], v), k
+    assert set(sio.load_file(path, names={"b.half"})) == {"b.half"}
+    try:
+        from safetensors.torch import load_file as st_load, save_file as st_save
+    except ImportError:
+        st_load = None
+    if st_load is not None:
+        theirs = st_load(path)
+        assert all(torch.equal(theirs[k], v) for k, v in sd.items())
+        p2 = str(tmp_path / "theirs.safetensors")
+        st_save({k: v.contiguous() for k, v in sd.items()}, p2)
+        ours = sio.load_file(p2)
+        assert all(torch.equal(ours[k], v) for k, v in sd.items())
+    raw = open(path, "rb").read()
+    bad = tmp_path / "bad.safetensors"
+    for blob, what in ((raw[:5], "shorter"), (struct.pack("<Q", 1 << 40) + raw[8:], "header length"),
+                       (struct.pack("<Q", 4) + b"nope" + raw[8:], "not JSON"), (raw[:-9], "claims bytes")):
+        bad.write_bytes(blob)
+        with pytest.raises(sio.SafetensorsError, match=what):
+            sio.load_file(str(bad))
+    n = struct.unpack("<Q", raw[:8])[0]
+    h = json.loads(raw[8:8 + n]); h["d.idx"]["shape"] = [2, 4]
+    js = json.dumps(h).encode(); bad.write_bytes(struct.pack("<Q", len(js)) + js + raw[8 + n:])
+    with pytest.raises(sio.SafetensorsError, match="claims bytes"):
+        sio.load_file(str(bad))

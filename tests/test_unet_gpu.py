@@ -625,3 +625,38 @@ def test_zero123pp_full_size_vs_oracle(dev):
           f"without the reference tokens {_rel(no_ref, want):.3e}")
     assert torch.isfinite(got).all() and r < 2.5e-3, r
     assert _rel(no_ref, want) > 4 * r
+
+
+def test_engines_load_safetensors_files(dev, tmp_path):
+    """Checkpoint-from-file path (the local stand-in for `from_pretrained`, src/stable_diffusion_depth.py:58-88): a diffusers-layout
+    directory written by this test (unet/ and vae/ safetensors in fp16 and fp32) loads through safetensors_io into the engines and
+    gives the same bits as load_state_dict of the same tensors; a file with a missing tensor is refused."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel
+    from contexture_nerf_amd.vae import AutoencoderKL
+    from contexture_nerf_amd.stable_diffusion_depth import StableDiffusion
+    from contexture_nerf_amd import safetensors_io as sio
+    from oracle import unet_ref, vae_ref
+    cfg = unet_ref.tiny_config()
+    torch.manual_seed(4)
+    ref = unet_ref.randomize_affine(unet_ref.UNet2DConditionModelRef(cfg)).eval()
+    sd16 = {k: v.half() for k, v in ref.state_dict().items()}
+    os.makedirs(tmp_path / "unet"); os.makedirs(tmp_path / "vae")
+    up = str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors")
+    sio.save_file(sd16, up)
+    a = UNet2DConditionModel(cfg, device=dev, init=False); a.load_state_dict({k: v.float() for k, v in sd16.items()})
+    b = UNet2DConditionModel.from_file(up, cfg, device=dev)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 16, 16, generator=g).to(dev); ctx = torch.randn(2, 7, cfg['cross_attention_dim'], generator=g).to(dev)
+    assert torch.equal(a(x, 300.0, ctx)['sample'], b(x, 300.0, ctx)['sample'])
+    vcfg = dict(latent_channels=4, out_channels=3, block_out_channels=(64, 128), layers_per_block=1, groups=32)
+    vref = vae_ref.AutoencoderKLRef(vcfg).eval()
+    vp = str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors")
+    sio.save_file(vref.state_dict(), vp)
+    va = AutoencoderKL(vcfg, device=dev, init=False); va.load_state_dict(vref.state_dict())
+    vb = AutoencoderKL.from_file(vp, vcfg, device=dev)
+    z = torch.randn(1, 4, 8, 8, generator=g).to(dev)
+    assert torch.equal(va.decode(z).sample, vb.decode(z).sample)
+    bad = dict(sd16); bad.pop("conv_in.weight")
+    sio.save_file(bad, up)
+    with pytest.raises(CtxError, match="missing"):
+        UNet2DConditionModel.from_file(up, cfg, device=dev)
