@@ -75,6 +75,9 @@ SIGNATURES = {
     "ctx_vae_encode_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
     "ctx_vae_encode": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ctx_vae_flops": (C.c_double, [_vp]),
+    "ctx_vae_encode_train_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32]),
+    "ctx_vae_encode_train": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "ctx_vae_encode_bwd": (_i32, [_vp, _vp, _f32, _vp, _vp]),
     "ctx_gemm_f16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ctx_conv3x3_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ctx_groupnorm_f16": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),

@@ -64,6 +64,10 @@ class OptimConfig:
     no_noise: bool = False
     learn_max_z_normals: bool = True
     alpha: float = -100
+    # additions of this build (not in the reference's OptimConfig):
+    views_in_flight: int = 3         # denoise loops a rank keeps in flight on one GPU (n HIP streams over one weight blob)
+    sds_iterations: int = 0          # 0: the per-view paint loop (north_star).  > 0: the reference's live paint() = paint_zero123plus
+                                     # with that many SDS iterations (the reference hard-codes 5000, src/training/trainer.py:662)
 
 
 @dataclass

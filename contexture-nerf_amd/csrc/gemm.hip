@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             int iy = xoy[i] + dy, ix = xox[i] + dx;
-            bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+            bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && !(a.zins && ((iy | ix) & 1));
             xp[i] = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 + xlc[i] : g_zero_page;
             xst[i] = ok ? PKT : 0;
         }
@@ -494,7 +494,8 @@ void ctx_gemm_plan(GemmArgs &a, bool conv)
 // split-K is counted; small problems fall through to tiles with more waves per staged byte.
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
 {
-    const int want8 = g_force_gemm8 >= 0 ? g_force_gemm8 : a.use8;          // -1: gemm8's own heuristic
+    if (a.zins) a.use8 = 0;                                                  // the zero-inserted grid exists in this file's kernel only
+    const int want8 = a.zins ? 0 : (g_force_gemm8 >= 0 ? g_force_gemm8 : a.use8);          // -1: gemm8's own heuristic
     const int want_tile = g_force_tile >= 0 ? g_force_tile : (g_force_gemm8 >= 0 ? -1 : a.tile);
     if (want_tile < 0 && conv && (want8 == 2 || want8 == 3) && ctx_conv_halo_try(a, want8 == 2 ? 2 : 1, s)) {
         if (a.splitk > 1) launch_reduce(a, s);

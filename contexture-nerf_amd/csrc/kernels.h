@@ -18,6 +18,8 @@ struct GemmArgs {
     int H, W, Cin, Ho, Wo, stride, ups;
     int poff;              // conv input-coordinate offset: 0 = symmetric padding 1; 1 = no top/left padding (diffusers' VAE
                            // Downsample2D: F.pad(x, (0,1,0,1)) then a stride-2 conv with padding 0)
+    int zins;              // conv: 1 = with ups, the 2x grid is ZERO-INSERTED (odd rows / columns read the zero page) instead of
+                           // nearest-upsampled: the input gradient of a stride-2 convolution (poff = -1 there); gemm.hip kernel only
     int ntm, ntn;
     int splitk;            // >1: grid.y = splitk, fp32 partials [splitk][M][N] go to `part`
     float *part;

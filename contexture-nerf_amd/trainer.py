@@ -245,6 +245,93 @@ class ConTEXTure:
                 self.mesh_model.export_mesh(str(self.cfg.log.exp_dir / 'mesh') if output_dir is None else str(output_dir) + '/mesh')
         return n
 
+    # ---- trainer.py:296-315 ---------------------------------------------------------------------------------
+    def init_zero123plus(self, unet=None, controlnet=None, vae=None, unet_config=None, vae_config=None):
+        """The Zero123++ stack the reference assembles from the hub (remote pipeline `sudo-ai/zero123plus-pipeline` + depth ControlNet
+        at conditioning scale 2, scheduler swapped for DDPMScheduler): here the same wrappers over the HIP engines —
+        DepthControlUNet(RefOnlyNoisedUNet(UNet in_channels 4)), AutoencoderKL, DDPMScheduler (v-prediction) as the pipeline's
+        scheduler.  Offline the weights are seeded random-init (or engines / state loaded by the caller); the CLIP-vision
+        `global_embeds` and the empty-prompt text embedding have no weights here and are a seeded random `prompt_embeds`."""
+        from .unet import UNet2DConditionModel, ControlNetModel, SD2_DEPTH
+        from .vae import AutoencoderKL
+        from .scheduler import DDPMScheduler
+        from .zero123plus import RefOnlyNoisedUNet, DepthControlUNet, Zero123PlusPipeline
+        ucfg = dict(SD2_DEPTH, in_channels=4) if unet_config is None else dict(unet_config)
+        seed = self.cfg.optim.seed
+        unet = unet if unet is not None else UNet2DConditionModel(ucfg, device=self.device, seed=seed + 11)
+        controlnet = controlnet if controlnet is not None else ControlNetModel(ucfg, device=self.device, seed=seed + 12)
+        vae = vae if vae is not None else AutoencoderKL(vae_config, device=self.device, seed=seed + 13)
+        # trainer.py:306-310: the pipeline's scheduler is replaced by a DDPMScheduler BEFORE prepare(), so RefOnlyNoisedUNet's
+        # val_sched (used in eval mode to noise the condition latent) is that same DDPM object
+        psched = DDPMScheduler(prediction_type="v_prediction")
+        stack = DepthControlUNet(RefOnlyNoisedUNet(unet, DDPMScheduler(prediction_type="v_prediction"), psched).eval(), controlnet,
+                                 conditioning_scale=2.0).eval()
+        self.zero123plus = Zero123PlusPipeline(vae, stack, psched)
+        g = torch.Generator().manual_seed(seed + 14)
+        self.zero123plus_prompt_embeds = torch.randn(1, 77, ucfg['cross_attention_dim'], generator=g).to(self.device)
+        return self.zero123plus
+
+    # ---- trainer.py:545-911 ---------------------------------------------------------------------------------
+    def paint_zero123plus(self, iterations=None, tile=320, on_iteration=None):
+        """The reference's live `paint()`: front view painted once with SD2-depth, then `iterations` (reference: 5000) steps of
+        score distillation of the UV-MLP against Zero123++ — render the 6 novel views from the cached raster, crop + resize to
+        tile^2, 3x2 grid, VAE encode WITH autograd, DreamTime timestep, one Zero123++ evaluation (reference-only attention +
+        depth ControlNet, CFG 10) -> v target -> `targets = z0 - grad`, 0.5 * sum-MSE on one random latent tile, backward through
+        the VAE encoder / resize / texture_mapping / texture field, Adam(lr 1e-5, betas (0.9, 0.99), eps 1e-15).
+        Host syncs of the reference's loop body that are hoisted out of it: the six crop boxes (the masks do not change) and the
+        DreamTime table (rebuilt every iteration there).  -> list of per-iteration dicts (loss, t, fisher, grad_norm)."""
+        from . import sds
+        from .scheduler import DDPMScheduler
+        if getattr(self, 'zero123plus', None) is None:
+            self.init_zero123plus()
+        pipe = self.zero123plus
+        iterations = int(iterations if iterations is not None else (self.cfg.optim.sds_iterations or 5000))
+        self.define_view_weights()
+        self.mesh_model.train()
+        gray = torch.tensor([0.5, 0.5, 0.5], device=self.device)
+        with torch.no_grad():
+            rgb_front, mask_front = self.paint_viewpoint(self.train_views[0], should_project_back=False)
+            thetas = [v['theta'] for v in self.train_views]
+            phis = [self._offset_phi(v['phi']) for v in self.train_views]
+            radii = [float(v['radius']) for v in self.train_views]
+            allv = self.mesh_model.render(theta=thetas, phi=phis, radius=radii, background=gray)
+            object_masks, depth_maps, render_cache = allv['mask'], 1.0 - allv['depth'], allv['render_cache']
+            B = object_masks.shape[0]
+            min_h, min_w, max_h, max_w = utils.get_nonzero_region_tuple(mask_front[0, 0])
+            rgba = torch.cat((rgb_front, mask_front), dim=1)[:, :, min_h:max_h, min_w:max_w]
+            # PIL's RGBA resize to 320x320 (bicubic, the library default) stands in as a bicubic interpolate; grey the transparent part
+            cond = sds.to_rgb_image(F.interpolate(rgba, (tile, tile), mode='bicubic', align_corners=False).clamp(0, 1))
+            cond_image = cond * 2 - 1
+            depth_grid = sds.build_depth_grid(depth_maps, object_masks, size=tile)
+            boxes = [utils.get_nonzero_region_tuple(object_masks[j, 0]) for j in range(1, B)]
+        self._sds_setup = dict(cond_image=cond_image, depth_grid=depth_grid, boxes=boxes, render_cache=render_cache)
+        params = [p for p in self.texture_mlp.parameters()]
+        optimizer = torch.optim.Adam(params, lr=1e-5, betas=(0.9, 0.99), eps=1e-15)
+        train_sched = DDPMScheduler(prediction_type="v_prediction")
+        alphas_cumprod = train_sched.alphas_cumprod.to(self.device)
+        dream = utils.DreamTimeScheduler(alphas_cumprod, iterations, m=500, s=125)
+        ikl, log = None, []
+        for i in range(iterations):
+            t = dream.get_t(i)
+            optimizer.zero_grad()
+            out = self.mesh_model.render(render_cache=render_cache, background=gray)
+            six = out['image'][1:]
+            tiles = [F.interpolate(six[j:j + 1, :, b[0]:b[2], b[1]:b[3]], (tile, tile), mode='bilinear', align_corners=False)
+                     for j, b in enumerate(boxes)]
+            r = sds.sds_iteration(pipe, torch.cat(tiles, 0), cond_image, depth_grid, self.zero123plus_prompt_embeds, t,
+                                  train_sched.alphas_cumprod, train_sched.add_noise, guidance_scale=10.0, grad_scale=0.2,
+                                  ikl_running_avg=ikl)
+            ikl = r['ikl_running_avg']
+            r['loss'].backward()
+            gn = torch.linalg.norm(torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None]))
+            optimizer.step()
+            rec = dict(i=i, t=int(t), loss=float(r['loss']), fisher=r['fisher'], ikl_running_avg=ikl, grad_norm=float(gn), index=r['index'])
+            log.append(rec)
+            if on_iteration is not None:
+                on_iteration(rec)
+        self.mesh_model.eval()
+        return log
+
     def paint(self, image_size=None, num_inference_steps=None):
         """Per-view paint loop with views sharded one per rank and one atlas all-reduce at the end."""
         n = len(self.train_views)

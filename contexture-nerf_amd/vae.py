@@ -124,8 +124,7 @@ class AutoencoderKL:
         L.check(self._lib.ctx_vae_decode(self._h, L.ptr(x, torch.float32, "latents"), B, H, W, L.ptr(out), L.stream()))
         return types.SimpleNamespace(sample=out)
 
-    def encode(self, x):
-        """x [B,3,H,W] in [-1,1] -> namespace(latent_dist=DiagonalGaussianDistribution-like with .sample() / .mode() / .mean / .logvar)."""
+    def _encode_nograd(self, x):
         if not self._has_encoder:
             raise L.CtxError("vae.encode: a decoder-only state_dict was loaded (no encoder.* / quant_conv.* parameters)")
         x = L.f32c(x, self.device)
@@ -145,6 +144,22 @@ class AutoencoderKL:
         mom = torch.empty(B, 2 * Lc, H // f, W // f, device=self.device)
         L.check(self._lib.ctx_vae_encode(self._h, L.ptr(x, torch.float32, "image"), B, H, W, L.ptr(mom), L.stream()))
         return types.SimpleNamespace(latent_dist=DiagonalGaussianDistribution(mom))
+
+    def encode_moments_with_grad(self, x):
+        """[B,3,H,W] in [-1,1] (may require grad) -> moments [B,2L,H/8,W/8] with autograd to x: the seam `vae.encode(...)` has in
+        the reference's SDS loop, where the loss is backpropagated THROUGH the frozen encoder into the rendered views
+        (src/training/trainer.py:732, 866).  Forward = ctx_vae_encode_train (keeps the tape in this engine's workspace),
+        backward = ctx_vae_encode_bwd; one backward per forward, no other call on this engine in between."""
+        return _VaeEncodeFn.apply(self, x)
+
+    def encode(self, x):
+        """x [B,3,H,W] in [-1,1] -> namespace(latent_dist=DiagonalGaussianDistribution-like with .sample() / .mode() / .mean / .logvar).
+        When x requires grad (and gradients are enabled) the moments carry the encoder's autograd."""
+        if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
+            if not self._has_encoder:
+                raise L.CtxError("vae.encode: a decoder-only state_dict was loaded (no encoder.* / quant_conv.* parameters)")
+            return types.SimpleNamespace(latent_dist=DiagonalGaussianDistribution(self.encode_moments_with_grad(x)))
+        return self._encode_nograd(x)
 
     def flops(self):
         return self._lib.ctx_vae_flops(self._h)
@@ -166,3 +181,39 @@ class DiagonalGaussianDistribution:
 
     def mode(self):
         return self.mean
+
+
+class _VaeEncodeFn(torch.autograd.Function):
+    """Autograd seam of AutoencoderKL.encode: forward / backward on the HIP engine (input gradient only: frozen VAE)."""
+
+    @staticmethod
+    def forward(ctx, vae, x):
+        x = L.f32c(x, vae.device)
+        B, Cc, H, W = x.shape
+        if Cc != vae.config['out_channels']:
+            raise L.CtxError(f"vae.encode: expected {vae.config['out_channels']} image channels, got {Cc}")
+        need = vae._lib.ctx_vae_encode_train_workspace_bytes(vae._h, B, H, W)
+        if need < 0:
+            f = 2 ** (len(vae.config['block_out_channels']) - 1)
+            raise L.CtxError(f"vae.encode: H, W must be multiples of {f} with (H/{f})*(W/{f}) a multiple of 64 (got {H}x{W})")
+        if vae._ws.numel() < need:
+            vae._ws = torch.empty(need, dtype=torch.uint8, device=vae.device)
+            vae._bind()
+        vae._ws_key = None
+        f = 2 ** (len(vae.config['block_out_channels']) - 1)
+        mom = torch.empty(B, 2 * vae.config['latent_channels'], H // f, W // f, device=vae.device)
+        L.check(vae._lib.ctx_vae_encode_train(vae._h, L.ptr(x, torch.float32, "image"), B, H, W, L.ptr(mom), L.stream()))
+        ctx.vae, ctx.shape = vae, (B, Cc, H, W)
+        return mom
+
+    @staticmethod
+    def backward(ctx, g):
+        vae = ctx.vae
+        g = L.f32c(g, vae.device)
+        gmax = float(g.abs().max())
+        if not (gmax > 0.0) or gmax != gmax or gmax == float('inf'):
+            return None, torch.zeros(ctx.shape, device=vae.device)
+        gscale = 2.0 ** round(__import__('math').log2(16.0 / gmax))          # fp16 gradients: max |g| scaled to ~16, a power of two
+        dx = torch.empty(ctx.shape, device=vae.device)
+        L.check(vae._lib.ctx_vae_encode_bwd(vae._h, L.ptr(g, torch.float32, "grad_moments"), gscale, L.ptr(dx), L.stream()))
+        return None, dx

@@ -242,6 +242,16 @@ int32_t ctx_vae_decoder_param_count(const ctx_vae_t *v);
 int64_t ctx_vae_encode_workspace_bytes(const ctx_vae_t *v, int32_t B, int32_t H, int32_t W);
 int32_t ctx_vae_encode(ctx_vae_t *v, const float *image, int32_t B, int32_t H, int32_t W, float *moments, ctx_stream_t stream);
 double ctx_vae_flops(const ctx_vae_t *v);     /* algorithmic FLOPs of the last decode / encode / dry run */
+/* Autograd of `vae.encode` in the reference's SDS loop (`loss.backward()` reaches the texture through
+   `vae.encode(rendered_grid_clean)`, src/training/trainer.py:732, 866; torch autograd over diffusers' Encoder there).
+   ctx_vae_encode_train = ctx_vae_encode that keeps what the backward needs (every GroupNorm input and the attention's q|k|v)
+   in the bound workspace; ctx_vae_encode_bwd consumes that tape once: grad_moments f32 NCHW [B, 2L, H/8, W/8] ->
+   grad_image f32 NCHW [B,3,H,W] (input gradients only: the VAE's parameters are frozen on this path).  Internally the
+   gradients are fp16 times `gscale` (choose it so that gscale * max|grad_moments| is O(1..100)); the result is exact in gscale.
+   Any other call on the handle between the two drops the tape (ctx_vae_encode_bwd then fails with CTX_E_ARG). */
+int64_t ctx_vae_encode_train_workspace_bytes(const ctx_vae_t *v, int32_t B, int32_t H, int32_t W);
+int32_t ctx_vae_encode_train(ctx_vae_t *v, const float *image, int32_t B, int32_t H, int32_t W, float *moments, ctx_stream_t stream);
+int32_t ctx_vae_encode_bwd(ctx_vae_t *v, const float *grad_moments, float gscale, float *grad_image, ctx_stream_t stream);
 
 /* Building blocks, exported for unit parity tests (fp16 tensors passed as uint16 bit patterns). */
 /* C[M,N] = A[M,K] @ Wt[N,K]^T (+bias[N]) (+residual[M,N]); K%64==0, N%8==0. */

@@ -19,7 +19,15 @@ def main(cfg: cfgmod.TrainConfig):
     os.makedirs(exp, exist_ok=True)
     cfgmod.dump(cfg, os.path.join(exp, 'config.yaml'))
     if cfg.log.eval_only:
-        raise SystemExit("eval_only: full_eval is out of scope of this build (SURVEY §3.5)")
+        n = trainer.full_eval()
+        print(f"full_eval: {n} views -> {exp}/results")
+        return
+    if cfg.optim.sds_iterations > 0:                    # the reference's live paint(): front view + SDS against Zero123++
+        log = trainer.paint_zero123plus(cfg.optim.sds_iterations)
+        if trainer.rank == 0:
+            print(f"SDS: {len(log)} iterations, last loss {log[-1]['loss']:.4f}")
+            trainer.full_eval(size=cfg.log.eval_size)
+        return
     atlas, coverage = trainer.paint()
     if trainer.rank == 0:
         torch.save({'atlas': atlas.cpu(), 'coverage': coverage.cpu()}, os.path.join(exp, 'atlas.pt'))

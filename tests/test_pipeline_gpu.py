@@ -237,3 +237,149 @@ def test_sds_iteration_targets(dev):
     assert abs(r['loss'].item() - 0.5 * split(r['grad'].float(), 8)[4].pow(2).sum().item()) <= 1e-4 * (1 + r['loss'].item())
     r2 = run()
     assert torch.equal(r2['v_pred'], r['v_pred']) and torch.equal(r2['targets'], r['targets'])
+
+
+def _tiny_zero123(dev, tr):
+    """Tiny Zero123++ stack with fp32 twins of its VAE for the oracle side."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel, ControlNetModel
+    from contexture_nerf_amd.vae import AutoencoderKL
+    from oracle import unet_ref, vae_ref
+    ucfg = unet_ref.tiny_config(in_channels=4)
+    vcfg = dict(latent_channels=4, out_channels=3, block_out_channels=(64, 128, 128, 128), layers_per_block=1, groups=32)
+    torch.manual_seed(31)
+    vref = unet_ref.randomize_affine(vae_ref.AutoencoderKLRef(vcfg)).eval()
+    vae = AutoencoderKL(vcfg, device=dev, init=False); vae.load_state_dict(vref.state_dict())
+    tr.init_zero123plus(unet=UNet2DConditionModel(ucfg, device=dev, seed=1), controlnet=ControlNetModel(ucfg, device=dev, seed=2), vae=vae,
+                        unet_config=ucfg)
+    return vref
+
+
+def test_sds_iteration_backward_vs_autograd_oracle(dev):
+    """ONE full iteration of the reference's SDS loop (src/training/trainer.py:700-866) on tiny engines: texture field -> cached
+    raster render of the 7 views -> six crops resized to tile^2 -> 3x2 grid -> VAE encode -> loss on one latent tile ->
+    backward.  The product's chain (HIP: VAE-encoder backward, texture_mapping backward, texture-field backward; torch only for
+    the crop/resize) against a plain torch fp32 autograd restatement of the SAME chain (torch MLP, F.grid_sample, the oracle's
+    Encoder) with the same noise sample and the same (detached) targets: every parameter gradient of the UV-MLP must agree."""
+    from contexture_nerf_amd import config as CFG, sds, utils
+    from contexture_nerf_amd.trainer import ConTEXTure
+    from contexture_nerf_amd.scheduler import DDPMScheduler
+    import types
+    cfg = CFG.TrainConfig()
+    cfg.guide.text = "a test mesh"; cfg.guide.shape_path = "shapes/spot_triangulated.obj"
+    cfg.guide.texture_resolution = 128; cfg.guide.sd_image_size = 128; cfg.guide.num_inference_steps = 2
+    cfg.render.train_grid_size = 192
+    sd, _, _ = _tiny_sd(dev)
+    tr = ConTEXTure(cfg, device=dev, diffusion=sd)
+    vref = _tiny_zero123(dev, tr)
+    pipe, tile = tr.zero123plus, 64
+    gray = torch.tensor([0.5, 0.5, 0.5], device=dev)
+    with torch.no_grad():
+        views = tr.train_views
+        allv = tr.mesh_model.render(theta=[v['theta'] for v in views], phi=[tr._offset_phi(v['phi']) for v in views],
+                                    radius=[float(v['radius']) for v in views], background=gray)
+        rc, masks = allv['render_cache'], allv['mask']
+        boxes = [utils.get_nonzero_region_tuple(masks[j, 0]) for j in range(1, 7)]
+        depth_grid = sds.build_depth_grid(1.0 - allv['depth'], masks, size=tile)
+    g = torch.Generator().manual_seed(3)
+    cond = (torch.rand(1, 3, tile, tile, generator=g) * 2 - 1).to(dev)
+    noise = torch.randn(1, 4, 3 * tile // 8, 2 * tile // 8, generator=g)
+    # a VAE shim that samples with a KNOWN noise tensor, so that the oracle can take the same sample
+    real_vae = pipe.vae
+
+    class FixedNoise:
+        def encode(self, x):
+            d = real_vae.encode(x).latent_dist
+            d.sample = lambda generator=None: d.mean + d.std * noise.to(dev)
+            return types.SimpleNamespace(latent_dist=d)
+
+        def __getattr__(self, k):
+            return getattr(real_vae, k)
+    pipe.vae = FixedNoise()
+    train_sched = DDPMScheduler(prediction_type="v_prediction")
+    params = list(tr.texture_mlp.parameters())
+    for p in params:
+        p.grad = None
+
+    def six_views(image):
+        return torch.cat([F.interpolate(image[1:][j:j + 1, :, b[0]:b[2], b[1]:b[3]], (tile, tile), mode='bilinear', align_corners=False)
+                          for j, b in enumerate(boxes)], 0)
+    out = tr.mesh_model.render(render_cache=rc, background=gray)
+    torch.manual_seed(17)
+    r = sds.sds_iteration(pipe, six_views(out['image']), cond, depth_grid, tr.zero123plus_prompt_embeds, 400, train_sched.alphas_cumprod,
+                          train_sched.add_noise, index_to_train=2)
+    r['loss'].backward()
+    got = [p.grad.detach().cpu().clone() for p in params]
+    assert all(torch.isfinite(gp).all() for gp in got) and float(r['loss']) > 0
+    # ---- torch fp32 autograd restatement -----------------------------------------------------------------------------
+    T = cfg.guide.texture_resolution
+    net = tr.texture_mlp
+    lin = [(l.weight.detach().cpu().clone().requires_grad_(True), l.bias.detach().cpu().clone().requires_grad_(True))
+           for l in list(net.pts_linears) + [net.output_linear]]
+    u = torch.stack(torch.meshgrid(torch.linspace(0, 1, T), torch.linspace(0, 1, T), indexing='xy'), dim=-1).reshape(-1, 2)
+    freqs = 2.0 ** torch.linspace(0, 9, 10)
+    emb = torch.cat([u] + [f(u * fr) for fr in freqs for f in (torch.sin, torch.cos)], -1)
+    h = emb
+    for i in range(8):
+        h = torch.relu(h @ lin[i][0].t() + lin[i][1])
+        if i == 4:
+            h = torch.cat([emb, h], -1)
+    mlp_out = h @ lin[8][0].t() + lin[8][1]
+    tex = ((mlp_out.tanh() + 1) / 2).reshape(1, T, T, 3).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        assert torch.allclose(tex, out['texture_map'].detach().cpu(), atol=2e-4)             # same atlas layout and values
+    uv = rc['uv_features'].cpu(); fidx = rc['face_idx'].cpu()
+    grid = torch.stack([uv[..., 0], 1 - uv[..., 1]], -1) * 2 - 1
+    feat = F.grid_sample(tex.expand(uv.shape[0], -1, -1, -1), grid, mode='bilinear', padding_mode='border', align_corners=False)
+    m = (fidx > -1).float()[:, None]
+    image = (gray.cpu().view(1, 3, 1, 1) * (1 - m) + feat * m * m).clamp(0, 1)
+    with torch.no_grad():
+        assert torch.allclose(image, out['image'].detach().cpu(), atol=3e-4)
+    six = six_views(image)
+    gridimg = utils.scale_image(sds.views_to_grid(six, tile) * 2 - 1)
+    mom = vref.encode_moments(gridimg)
+    mean, logvar = mom.chunk(2, 1)
+    z0 = utils.scale_latents((mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * noise) * sds.VAE_SCALING)
+    with torch.no_grad():
+        rz = float((z0 - r['z0'].detach().cpu()).norm() / z0.norm())
+        assert rz < 5e-3, rz
+    loss, _ = sds.tile_loss(z0, r['targets'].detach().cpu(), 2)
+    loss.backward()
+    assert abs(float(loss) - float(r['loss'])) <= 2e-2 * abs(float(loss)) + 1e-6
+    num = sum(float(((a - w_.grad) ** 2).sum()) for a, (w_, b_) in zip(got[0::2], lin)) + \
+        sum(float(((a - b_.grad) ** 2).sum()) for a, (w_, b_) in zip(got[1::2], lin))
+    den = sum(float((w_.grad ** 2).sum()) + float((b_.grad ** 2).sum()) for (w_, b_) in lin)
+    rel = (num / den) ** 0.5
+    print(f"SDS iteration: loss {float(r['loss']):.4f} (oracle {float(loss):.4f}), rel L2 of the UV-MLP parameter gradient vs torch autograd = {rel:.3e}")
+    assert den > 0 and rel < 2e-2, rel
+    pipe.vae = real_vae
+
+
+def test_paint_zero123plus_loop_and_eval(dev, tmp_path):
+    """The reference's live paint(): front view painted with SD2-depth, then SDS iterations with Adam on the UV-MLP
+    (paint_zero123plus, trainer.py:545-911) on tiny engines — runs, every record is finite, the parameters move, the DreamTime
+    timesteps descend from the noisy end; then the eval orbit (full_eval, :913-968) writes its frames, atlas and mesh."""
+    import os
+    from contexture_nerf_amd import config as CFG
+    from contexture_nerf_amd.trainer import ConTEXTure
+    cfg = CFG.TrainConfig()
+    cfg.guide.text = "a test mesh"; cfg.guide.shape_path = "shapes/spot_triangulated.obj"
+    cfg.guide.texture_resolution = 128; cfg.guide.sd_image_size = 128; cfg.guide.num_inference_steps = 2
+    cfg.render.train_grid_size = 192; cfg.render.eval_grid_size = 96
+    cfg.log.exp_root = tmp_path; cfg.log.exp_name = "sds"; cfg.log.full_eval_size = 5
+    sd, _, _ = _tiny_sd(dev)
+    tr = ConTEXTure(cfg, device=dev, diffusion=sd)
+    _tiny_zero123(dev, tr)
+    before = [p.detach().clone() for p in tr.texture_mlp.parameters()]
+    log = tr.paint_zero123plus(iterations=4, tile=64)
+    assert [r['i'] for r in log] == [0, 1, 2, 3] and all(np.isfinite(r['loss']) and np.isfinite(r['grad_norm']) and r['grad_norm'] > 0 for r in log)
+    assert log[0]['t'] >= log[-1]['t'] and log[0]['t'] > 900
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, tr.texture_mlp.parameters()))
+    n = tr.full_eval()
+    out = cfg.log.exp_dir / 'results'
+    assert n == 5 and len([f for f in os.listdir(out) if f.endswith('_rgb.jpg')]) == 5
+    assert os.path.exists(out / "eval:texture_atlas:texture.png") and os.path.exists(cfg.log.exp_dir / 'mesh' / 'mesh.obj')
+    # should_project_back (the reference's default): the painted view lands in the running atlas and the fitted render returns
+    rgb, obj = tr.paint_viewpoint(tr.train_views[1])
+    assert tr.fitted_pred_rgb.shape == rgb.shape and float(tr.atlas_contrib[3].sum()) > 0
+    m = (obj > 0).expand_as(rgb)
+    assert float((tr.fitted_pred_rgb - rgb)[m].abs().mean()) < 0.08       # the scattered atlas reproduces the view it was painted from
