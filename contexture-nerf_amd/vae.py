@@ -39,12 +39,42 @@ class AutoencoderKL:
         self._n_dec = self._lib.ctx_vae_decoder_param_count(self._h)
         self._has_encoder = True
         self._ws_key = None
+        self._tape_pending = False       # a training forward's tape lives in this engine's workspace until its backward runs
+        self._sibling = None
         if self.device.type == 'cuda':
             self._weights = torch.empty(self._lib.ctx_vae_weight_bytes(self._h), dtype=torch.uint8, device=self.device)
             self._ws = torch.empty(256, dtype=torch.uint8, device=self.device)
             self._bind()
             if init:
                 self.init_random(seed)
+
+    def clone_shared(self):
+        """A second engine handle over the SAME weight blob with its own workspace (as UNet2DConditionModel.clone_shared)."""
+        o = AutoencoderKL.__new__(AutoencoderKL)
+        o.config, o.device, o._lib = self.config, self.device, self._lib
+        ch = [int(c) for c in self.config['block_out_channels']]
+        c = VAEConfig(self.config['latent_channels'], self.config['out_channels'], len(ch), (C.c_int32 * 4)(*(ch + [0] * (4 - len(ch)))),
+                      self.config['layers_per_block'], self.config['groups'])
+        o._h = self._lib.ctx_vae_create(C.byref(c))
+        if not o._h:
+            raise L.CtxError("ctx_vae_create: " + self._lib.ctx_last_error().decode())
+        o._names, o._shapes, o._index, o._n_dec = self._names, self._shapes, self._index, self._n_dec
+        o._has_encoder, o._ws_key, o._tape_pending, o._sibling = self._has_encoder, None, False, None
+        o._weights = self._weights
+        o._ws = torch.empty(256, dtype=torch.uint8, device=self.device)
+        o._bind()
+        return o
+
+    def _free_engine(self):
+        """The engine to run a no-grad call on: this one, unless it holds the tape of a training forward whose backward is still
+        to come (the SDS loop encodes the condition image between the grid's encode and loss.backward()): then a sibling handle
+        over the same weights with its own workspace."""
+        if not self._tape_pending:
+            return self
+        if self._sibling is None:
+            self._sibling = self.clone_shared()
+        self._sibling._has_encoder = self._has_encoder
+        return self._sibling
 
     def __del__(self):
         try:
@@ -106,6 +136,9 @@ class AutoencoderKL:
         torch.cuda.synchronize(self.device)
 
     def decode(self, z):
+        eng = self._free_engine()
+        if eng is not self:
+            return eng.decode(z)
         x = L.f32c(z, self.device)
         B, Lc, H, W = x.shape
         if Lc != self.config['latent_channels']:
@@ -125,6 +158,9 @@ class AutoencoderKL:
         return types.SimpleNamespace(sample=out)
 
     def _encode_nograd(self, x):
+        eng = self._free_engine()
+        if eng is not self:
+            return eng._encode_nograd(x)
         if not self._has_encoder:
             raise L.CtxError("vae.encode: a decoder-only state_dict was loaded (no encoder.* / quant_conv.* parameters)")
         x = L.f32c(x, self.device)
@@ -192,6 +228,8 @@ class _VaeEncodeFn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         if Cc != vae.config['out_channels']:
             raise L.CtxError(f"vae.encode: expected {vae.config['out_channels']} image channels, got {Cc}")
+        if vae._tape_pending:
+            raise L.CtxError("vae.encode: a training forward of this engine still waits for its backward (one tape per engine)")
         need = vae._lib.ctx_vae_encode_train_workspace_bytes(vae._h, B, H, W)
         if need < 0:
             f = 2 ** (len(vae.config['block_out_channels']) - 1)
@@ -204,11 +242,13 @@ class _VaeEncodeFn(torch.autograd.Function):
         mom = torch.empty(B, 2 * vae.config['latent_channels'], H // f, W // f, device=vae.device)
         L.check(vae._lib.ctx_vae_encode_train(vae._h, L.ptr(x, torch.float32, "image"), B, H, W, L.ptr(mom), L.stream()))
         ctx.vae, ctx.shape = vae, (B, Cc, H, W)
+        vae._tape_pending = True
         return mom
 
     @staticmethod
     def backward(ctx, g):
         vae = ctx.vae
+        vae._tape_pending = False
         g = L.f32c(g, vae.device)
         gmax = float(g.abs().max())
         if not (gmax > 0.0) or gmax != gmax or gmax == float('inf'):

@@ -289,7 +289,8 @@ def test_sds_iteration_backward_vs_autograd_oracle(dev):
     class FixedNoise:
         def encode(self, x):
             d = real_vae.encode(x).latent_dist
-            d.sample = lambda generator=None: d.mean + d.std * noise.to(dev)
+            if d.mean.shape == noise.shape:             # the view grid; the condition image's own encode keeps its random sample
+                d.sample = lambda generator=None: d.mean + d.std * noise.to(dev)
             return types.SimpleNamespace(latent_dist=d)
 
         def __getattr__(self, k):
