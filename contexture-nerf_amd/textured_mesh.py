@@ -62,8 +62,10 @@ class TexturedMeshModel(torch.nn.Module):
         cache_path = self.cache_path
         if cache_path is not None:
             vt_cache, ft_cache = os.path.join(str(cache_path), 'vt.pth'), os.path.join(str(cache_path), 'ft.pth')
+        # the reference takes the file's UVs whenever ft.min() > -1 (textured_mesh.py:380-381); shapes/sphere.obj carries 960 vt
+        # lines that are ALL (0, 0) — every face would land on one texel — so a chart of zero extent also falls through to the atlas
         if self.mesh.vt is not None and self.mesh.ft is not None and self.mesh.vt.shape[0] > 0 and self.mesh.ft.numel() > 0 \
-                and self.mesh.ft.min() > -1:
+                and self.mesh.ft.min() > -1 and float((self.mesh.vt.max(0).values - self.mesh.vt.min(0).values).min()) > 0:
             vt, ft = self.mesh.vt.to(self.device), self.mesh.ft.to(self.device)
         elif cache_path is not None and os.path.exists(vt_cache) and os.path.exists(ft_cache):
             vt = torch.load(vt_cache, weights_only=True).to(self.device)

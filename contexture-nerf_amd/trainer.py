@@ -325,7 +325,7 @@ class ConTEXTure:
             r['loss'].backward()
             gn = torch.linalg.norm(torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None]))
             optimizer.step()
-            rec = dict(i=i, t=int(t), loss=float(r['loss']), fisher=r['fisher'], ikl_running_avg=ikl, grad_norm=float(gn), index=r['index'])
+            rec = dict(i=i, t=int(t), loss=float(r['loss'].detach()), fisher=r['fisher'], ikl_running_avg=ikl, grad_norm=float(gn), index=r['index'])
             log.append(rec)
             if on_iteration is not None:
                 on_iteration(rec)
