@@ -26,6 +26,10 @@ SIGNATURES = {
     "ctx_normalize_depth": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ctx_texture_mapping_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctx_texture_mapping_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ctx_texmap_bwd_plan_bytes": (_i64, [_i32, _i32, _i32]),
+    "ctx_texmap_bwd_plan": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "ctx_texture_mapping_bwd_binned_ws_bytes": (_i64, [_i32, _i32]),
+    "ctx_texture_mapping_bwd_binned": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ctx_texture_pack4": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "ctx_texture_mapping_packed_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctx_view_weights_max": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -138,38 +138,39 @@ __global__ __launch_bounds__(256) void k_raster_setup(const float *__restrict__ 
     bbox[(size_t)b * F + f] = make_float4(r.xmin, r.xmax, r.ymin, r.ymax);   // compact copy: 16 B per face for the culls
 }
 
+// grid (coarse tiles, face-range groups, views): with few views a tile's face scan is cut into `gridDim.y` ranges so that the launch
+// still has >= ~1000 workgroups; a group appends its survivors to the tile's list behind one global reservation per wave (the list
+// order is then arbitrary: the fine kernel's winner rule does not depend on it).  `counts` is zeroed by the caller.
 __global__ __launch_bounds__(256) void k_raster_bin(int H, int W, const float4 *__restrict__ bbox, int F, float mult,
                                                     int ntx, int nty, int *__restrict__ lists,
                                                     int *__restrict__ counts)
 {
-    int b = blockIdx.y;
+    int b = blockIdx.z;
     int tile = blockIdx.x;
     int tx = tile % ntx, ty = tile / ntx;
     int i0 = tx * COARSE, i1 = min(W, i0 + COARSE) - 1;
     int j0 = ty * COARSE, j1 = min(H, j0 + COARSE) - 1;
     float xlo = pix_x(i0, W, mult), xhi = pix_x(i1, W, mult);
     float yhi = pix_y(j0, H, mult), ylo = pix_y(j1, H, mult);
-    __shared__ int s_count;
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
     int *list = lists + ((size_t)b * ntx * nty + tile) * F;
+    int *cnt = counts + (size_t)b * ntx * nty + tile;
     const float4 *bbv = bbox + (size_t)b * F;
-    for (int f0 = 0; f0 < F; f0 += 256) {
+    const int per = ((F + (int)gridDim.y - 1) / (int)gridDim.y + 255) & ~255;
+    const int fbeg = blockIdx.y * per, fend = min(F, fbeg + per);
+    for (int f0 = fbeg; f0 < fend; f0 += 256) {
         int f = f0 + threadIdx.x;
         bool keep = false;
-        if (f < F) {
+        if (f < fend) {
             const float4 bb = bbv[f];                             // xmin, xmax, ymin, ymax
             keep = !(xhi < bb.x || xlo >= bb.y || yhi < bb.z || ylo >= bb.w);
         }
         unsigned long long m = __ballot(keep);
         int lane = threadIdx.x & 63;
         int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&s_count, __popcll(m));
+        if (lane == 0 && m) base = atomicAdd(cnt, __popcll(m));
         base = __shfl(base, 0, 64);
         if (keep) list[base + __popcll(m & ((1ull << lane) - 1))] = f;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) counts[(size_t)b * ntx * nty + tile] = s_count;
 }
 
 template <bool FUSED>
@@ -292,7 +293,10 @@ static int32_t raster_common(bool fused, int H, int W, const float *fz, int zstr
     int *lists = (int *)(bbox + (size_t)B * F);
     int *counts = lists + (size_t)B * ntx * nty * F;
     hipLaunchKernelGGL(k_raster_setup, dim3(cdiv(F, 256), B), dim3(256), 0, s, fz, zstride, fxy, F, mult, recs, bbox);
-    hipLaunchKernelGGL(k_raster_bin, dim3(ntx * nty, B), dim3(256), 0, s, H, W, bbox, F, mult, ntx, nty, lists, counts);
+    (void)hipMemsetAsync(counts, 0, (size_t)B * ntx * nty * sizeof(int), s);
+    int G = cdiv(1024, ntx * nty * B);                          // face-range groups per tile: keep the bin launch >= ~1000 workgroups
+    G = max(1, min(min(G, 8), cdiv(F, 256)));
+    hipLaunchKernelGGL(k_raster_bin, dim3(ntx * nty, G, B), dim3(256), 0, s, H, W, bbox, F, mult, ntx, nty, lists, counts);
     dim3 grid(cdiv(W, FT_W), cdiv(H, FT_H), B);
     if (fused)
         hipLaunchKernelGGL(k_raster<true>, grid, dim3(256), 0, s, H, W, fz, zstride, recs, bbox, feat, featB, C, fnorm, F, mult, eps,

@@ -107,6 +107,39 @@ def rasterize_fused(height, width, face_vertices_camera, face_vertices_image, uv
     return depth, uv, idx, normals
 
 
+_PLANS = {}          # (uv ptr, uv version, mask ptr, shape, T) -> (plan buffer, uv, mask): binning of a raster, reused across backwards
+
+
+def scatter_add_texture(go, uv, mask_idx, grad_tex, binned=None):
+    """grad_tex [C,T,T] += bilinear scatter of go [B,H,W,C] (or [B,HW,C]) at uv — the backward of texture_mapping and the UV
+    back-projection scatter.  Large rasters (>= 64k pixels, C <= 4) go through the binned, atomics-free path of uvscatter.hip:
+    its plan depends on (uv, mask) only and is kept for the next call on the same raster (the SDS loop's render_cache)."""
+    lib = L.load()
+    B = uv.shape[0]
+    HW = uv[0].numel() // 2
+    C, T = grad_tex.shape[0], grad_tex.shape[-1]
+    use = (B * HW >= 65536 and C <= 4) if binned is None else binned
+    if not use:
+        L.check(lib.ctx_texture_mapping_bwd(L.ptr(go, torch.float32, "grad_out"), L.ptr(uv, torch.float32, "uv"), B, HW, C, T,
+                                            L.ptr(mask_idx), L.ptr(grad_tex, torch.float32, "grad_tex"), L.stream()))
+        return grad_tex
+    key = (uv.data_ptr(), uv._version, None if mask_idx is None else (mask_idx.data_ptr(), mask_idx._version), B, HW, T)
+    ent = _PLANS.get(key)
+    if ent is None:
+        nbytes = lib.ctx_texmap_bwd_plan_bytes(B, HW, T)
+        if nbytes < 0:
+            raise L.CtxError(f"scatter_add_texture: B*HW = {B * HW} pixels do not fit the binned path")
+        plan = torch.empty(nbytes, dtype=torch.uint8, device=uv.device)
+        L.check(lib.ctx_texmap_bwd_plan(L.ptr(uv, torch.float32, "uv"), L.ptr(mask_idx), B, HW, T, L.ptr(plan), L.stream()))
+        while len(_PLANS) >= 4:
+            _PLANS.pop(next(iter(_PLANS)))
+        ent = _PLANS[key] = (plan, uv, mask_idx)      # keep uv / mask alive: the key is their address
+    ws = torch.empty(lib.ctx_texture_mapping_bwd_binned_ws_bytes(C, T), dtype=torch.uint8, device=uv.device)
+    L.check(lib.ctx_texture_mapping_bwd_binned(L.ptr(go, torch.float32, "grad_out"), L.ptr(uv, torch.float32, "uv"), B, HW, C, T, L.ptr(ent[0]),
+                                               L.ptr(ws), L.ptr(grad_tex, torch.float32, "grad_tex"), L.stream()))
+    return grad_tex
+
+
 class _TextureMapping(torch.autograd.Function):
     @staticmethod
     def forward(ctx, uv, tex, mode, mask_idx):
@@ -149,8 +182,7 @@ class _TextureMapping(torch.autograd.Function):
         go = L.f32c(grad_out)
         if Bt_eff == 1:
             g = torch.zeros(Cc, T, T, device=go.device)
-            L.check(lib.ctx_texture_mapping_bwd(L.ptr(go), L.ptr(uvc), B, HW, Cc, T, L.ptr(mask_idx if has_mask else None),
-                                                L.ptr(g), L.stream()))
+            scatter_add_texture(go, uvc, mask_idx if has_mask else None, g)
             if Bt > 1:      # input was an expand(): autograd sums the batch slices, so put the whole sum in slice 0
                 full = torch.zeros(tshape, device=go.device)
                 full[0] = g

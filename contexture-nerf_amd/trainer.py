@@ -141,16 +141,15 @@ class ConTEXTure:
     def project_back_scatter(self, render_cache, rgb_output, weight_mask):
         """Scatter a painted view into the atlas: contrib[0:3] += w*rgb, contrib[3] += w at the 4 bilinear texels of
         each visible pixel (w = view weight mask).  Implemented with the texture-sampling backward kernel."""
-        lib = L.load()
+        from . import kal
         uv = render_cache['uv_features']
         face_idx = render_cache['face_idx']
-        B, H, W, _ = uv.shape
         T = self.cfg.guide.texture_resolution
         w = weight_mask.to(torch.float32).permute(0, 2, 3, 1)
         go = torch.cat([rgb_output.permute(0, 2, 3, 1) * w, w], dim=-1).contiguous()
         contrib = torch.zeros(4, T, T, device=uv.device)
-        L.check(lib.ctx_texture_mapping_bwd(L.ptr(go, torch.float32), L.ptr(L.f32c(uv)), B, H * W, 4, T,
-                                            L.ptr(face_idx.contiguous(), torch.int64), L.ptr(contrib), L.stream()))
+        uvc = uv if (uv.dtype == torch.float32 and uv.is_contiguous()) else L.f32c(uv)
+        kal.scatter_add_texture(go, uvc, face_idx.contiguous(), contrib)
         return contrib
 
     @torch.no_grad()

@@ -78,6 +78,15 @@ int32_t ctx_texture_mapping_fwd(const float *uv, const float *tex, int32_t B, in
 int32_t ctx_texture_mapping_bwd(const float *grad_out, const float *uv, int32_t B, int32_t HW,
                                 int32_t C, int32_t T, const int64_t *mask_idx, float *grad_tex,
                                 ctx_stream_t stream);
+/* The same scatter without global float atomics (uvscatter.hip): pixels are binned by 32 x 32-texel atlas tile once per raster
+   (`plan`: depends on uv / mask_idx only, reusable by every backward of the SDS loop), then one workgroup per tile accumulates
+   its pixel list in LDS as 2^-32 fixed-point int64 sums and writes each texel once.  Bit-reproducible (integer sums do not depend
+   on arrival order); C <= 4, B*HW < 2^32.  grad_tex [C,T,T] is added to (as above).  ws: ctx_texture_mapping_bwd_binned_ws_bytes. */
+int64_t ctx_texmap_bwd_plan_bytes(int32_t B, int32_t HW, int32_t T);
+int32_t ctx_texmap_bwd_plan(const float *uv, const int64_t *mask_idx, int32_t B, int32_t HW, int32_t T, void *plan, ctx_stream_t stream);
+int64_t ctx_texture_mapping_bwd_binned_ws_bytes(int32_t C, int32_t T);
+int32_t ctx_texture_mapping_bwd_binned(const float *grad_out, const float *uv, int32_t B, int32_t HW, int32_t C, int32_t T,
+                                       const void *plan, void *ws, float *grad_tex, ctx_stream_t stream);
 
 /* Texel-interleaved forward for C <= 4 and one texture shared by the batch (the reference's texture_img.expand(B, ...),
    render.py:133-135): ctx_texture_pack4 repacks [C,T,T] into [T,T,4] once, ctx_texture_mapping_packed_fwd then gathers one

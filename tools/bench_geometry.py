@@ -67,6 +67,14 @@ go = torch.rand(B, H, W, 3, device=dev)
 uvc = uv.contiguous(); g = torch.zeros(3, T, T, device=dev)
 report("texture_mapping bwd (atlas scatter) B=7 @1200^2", timeit(lambda: L.check(lib.ctx_texture_mapping_bwd(L.ptr(go), L.ptr(uvc), B, H * W, 3, T, L.ptr(idx), L.ptr(g), L.stream()))),
        bytes_=B * H * W * (8 + 12 + 8) + 2 * 3 * T * T * 4)
+# the binned, atomics-free scatter (uvscatter.hip): plan built once per raster, then the per-backward scatter alone
+plan = torch.empty(lib.ctx_texmap_bwd_plan_bytes(B, H * W, T), dtype=torch.uint8, device=dev)
+wsb = torch.empty(lib.ctx_texture_mapping_bwd_binned_ws_bytes(3, T), dtype=torch.uint8, device=dev)
+report("UV scatter plan (bin pixels by atlas tile; once per raster) B=7 @1200^2",
+       timeit(lambda: L.check(lib.ctx_texmap_bwd_plan(L.ptr(uvc), L.ptr(idx), B, H * W, T, L.ptr(plan), L.stream()))), bytes_=B * H * W * (8 + 8) * 2)
+report("texture_mapping bwd binned (LDS tiles, no global float atomics; cached plan) B=7 @1200^2",
+       timeit(lambda: L.check(lib.ctx_texture_mapping_bwd_binned(L.ptr(go), L.ptr(uvc), B, H * W, 3, T, L.ptr(plan), L.ptr(wsb), L.ptr(g), L.stream()))),
+       bytes_=B * H * W * (8 + 12 + 8) + 2 * 3 * T * T * 4)
 fnp = fn.permute(0, 2, 1).contiguous()
 idx6 = idx[1:, None].contiguous(); fn6 = fnp[1:].contiguous()
 report("view weights (scatter_max seam) B=6 @1200^2", timeit(lambda: vw.view_weight_masks(idx6, fn6)), bytes_=6 * H * W * (8 + 8 + 1) + 6 * F_ * 4)
