@@ -64,6 +64,7 @@ SIGNATURES = {
     "ctx_unet_ref_bank_bytes": (_i64, [_vp, _i32, _i32, _i32]),
     "ctx_unet_workspace_bytes_ref": (_i64, [_vp, _i32, _i32, _i32, _i32, _i32, _i32]),
     "ctx_unet_forward_ref": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "ctx_unet_set_residual_fp32": (_i32, [_vp, _i32]),
     "ctx_unet_stats": (_i32, [_vp, _i32, _vp, _vp]),
     "ctx_vae_create": (_vp, [_vp]),
     "ctx_vae_destroy": (None, [_vp]),

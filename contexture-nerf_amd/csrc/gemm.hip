@@ -84,14 +84,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
                         for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
                     }
                     if (a.residual) {
-                        f16x4 b = *(const f16x4 *)(a.residual + (size_t)m * a.ldr + nn);
+                        if (a.res32) {
+                            f32x4 b = *(const f32x4 *)((const float *)a.residual + (size_t)m * a.ldr + nn);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
+                            for (int j = 0; j < 4; ++j) v[j] += b[j];
+                        } else {
+                            f16x4 b = *(const f16x4 *)(a.residual + (size_t)m * a.ldr + nn);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
+                        }
                     }
-                    f16x4 o;
+                    if (a.out32) {
+                        *(f32x4 *)((float *)a.out + (size_t)m * a.ldc + nn) = (f32x4){v[0], v[1], v[2], v[3]};
+                    } else {
+                        f16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
-                    *(f16x4 *)(a.out + (size_t)m * a.ldc + nn) = o;
+                        for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
+                        *(f16x4 *)(a.out + (size_t)m * a.ldc + nn) = o;
+                    }
                 }
         }
     }
@@ -137,14 +147,26 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs &a, f32x16 (
                     for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
                 }
                 if (a.residual) {
-                    f16x8 b = *(const f16x8 *)(a.residual + (size_t)m * a.ldr + n);
+                    if (a.res32) {
+                        const float *rp = (const float *)a.residual + (size_t)m * a.ldr + n;
+                        f32x4 b0 = *(const f32x4 *)rp, b1 = *(const f32x4 *)(rp + 4);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
+                        for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+                    } else {
+                        f16x8 b = *(const f16x8 *)(a.residual + (size_t)m * a.ldr + n);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
+                    }
                 }
-                f16x8 o;
+                if (a.out32) {
+                    float *op = (float *)a.out + (size_t)m * a.ldc + n;
+                    *(f32x4 *)op = (f32x4){v[0], v[1], v[2], v[3]}; *(f32x4 *)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    f16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
-                *(f16x8 *)(a.out + (size_t)m * a.ldc + n) = o;
+                    for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
+                    *(f16x8 *)(a.out + (size_t)m * a.ldc + n) = o;
+                }
             }
         }
     }
@@ -371,7 +393,11 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a)
             f16x4 b = *(const f16x4 *)(a.rowbias + (size_t)(m / a.rows_per_batch) * a.ldrb + nn);
             for (int j = 0; j < 4; ++j) v[j] += (float)b[j];
         }
-        if (a.residual) { f16x4 b = *(const f16x4 *)(a.residual + (size_t)m * a.ldr + nn); for (int j = 0; j < 4; ++j) v[j] += (float)b[j]; }
+        if (a.residual) {
+            if (a.res32) { f32x4 b = *(const f32x4 *)((const float *)a.residual + (size_t)m * a.ldr + nn); v += b; }
+            else { f16x4 b = *(const f16x4 *)(a.residual + (size_t)m * a.ldr + nn); for (int j = 0; j < 4; ++j) v[j] += (float)b[j]; }
+        }
+        if (a.out32) { *(f32x4 *)((float *)a.out + (size_t)m * a.ldc + nn) = v; continue; }
         f16x4 o;
         for (int j = 0; j < 4; ++j) o[j] = (f16)v[j];
         *(f16x4 *)(a.out + (size_t)m * a.ldc + nn) = o;
@@ -494,8 +520,9 @@ void ctx_gemm_plan(GemmArgs &a, bool conv)
 // split-K is counted; small problems fall through to tiles with more waves per staged byte.
 int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
 {
-    if (a.zins) a.use8 = 0;                                                  // the zero-inserted grid exists in this file's kernel only
-    const int want8 = a.zins ? 0 : (g_force_gemm8 >= 0 ? g_force_gemm8 : a.use8);          // -1: gemm8's own heuristic
+    const bool only_pipe = a.zins || a.res32 || a.out32;                     // features of this file's kernel only
+    if (only_pipe) a.use8 = 0;
+    const int want8 = only_pipe ? 0 : (g_force_gemm8 >= 0 ? g_force_gemm8 : a.use8);          // -1: gemm8's own heuristic
     const int want_tile = g_force_tile >= 0 ? g_force_tile : (g_force_gemm8 >= 0 ? -1 : a.tile);
     if (want_tile < 0 && conv && (want8 == 2 || want8 == 3) && ctx_conv_halo_try(a, want8 == 2 ? 2 : 1, s)) {
         if (a.splitk > 1) launch_reduce(a, s);

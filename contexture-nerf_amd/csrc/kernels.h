@@ -18,6 +18,7 @@ struct GemmArgs {
     int H, W, Cin, Ho, Wo, stride, ups;
     int poff;              // conv input-coordinate offset: 0 = symmetric padding 1; 1 = no top/left padding (diffusers' VAE
                            // Downsample2D: F.pad(x, (0,1,0,1)) then a stride-2 conv with padding 0)
+    int res32, out32;      // 1: `residual` / `out` point at fp32 tensors (the fp32 residual-stream experiment; gemm.hip epilogues only)
     int zins;              // conv: 1 = with ups, the 2x grid is ZERO-INSERTED (odd rows / columns read the zero page) instead of
                            // nearest-upsampled: the input gradient of a stride-2 convolution (poff = -1 there); gemm.hip kernel only
     int ntm, ntn;
@@ -49,6 +50,12 @@ int ctx_conv_out_f16(const f16 *x, const f16 *w, const f16 *bias, int B, int H, 
 int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, int Skv, int heads, int q_stride,
                        int kv_stride, float scale, f16 *O, int o_stride, hipStream_t s);
 extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups);
+// norms over the fp32 residual stream (x32 != 0) or fp16 activations; output fp16
+int ctx_groupnorm_any(const void *x, int x32, const void *gamma, const void *beta, int B, int HW, int C, int groups, float eps, int silu,
+                      void *y, void *stats_ws, hipStream_t stream);
+int ctx_layernorm_any(const void *x, int x32, const void *gamma, const void *beta, int64_t rows, int C, float eps, void *y, hipStream_t stream);
+int ctx_concat_f32(const float *a, const float *b, int64_t M, int Ca, int Cb, float *y, hipStream_t s);
+int ctx_f16_to_f32(const f16 *x, int64_t n, float *y, hipStream_t s);
 
 // profiling hooks (api.cpp): when on, MFMA kernels are launched with hipExtLaunchKernelGGL start/stop events
 bool ctx_prof_on(void);

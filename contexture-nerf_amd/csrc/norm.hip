@@ -15,13 +15,32 @@
 // up to GN_U pixels of its split, all loaded before the first add; per-channel partials -> LDS -> per-group sums.
 // Pass 2: grid (nb, B); a thread issues its GN_AU 16-byte loads first, then the block folds the NS split partials
 // per (b, group) in a fixed order (deterministic: no float atomics anywhere in GroupNorm) while they fly.
+// 8 consecutive channels of the input as floats: fp16 activations (16 bytes) or the fp32 residual stream (32 bytes)
+struct F8 { float v[8]; };
+template <bool X32>
+__device__ __forceinline__ F8 ld8(const void *base, size_t elem)
+{
+    F8 r;
+    if (X32) {
+        const f32x4 a = *(const f32x4 *)((const float *)base + elem), b = *(const f32x4 *)((const float *)base + elem + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { r.v[j] = a[j]; r.v[4 + j] = b[j]; }
+    } else {
+        const f16x8 a = *(const f16x8 *)((const f16 *)base + elem);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.v[j] = (float)a[j];
+    }
+    return r;
+}
+
 #define GN_MAX_GROUPS 64
 #define GN_MAX_SPLITS 128
 #define GN_MAX_C 4096
 #define GN_U 4
 #define GN_AU 4
 
-__global__ __launch_bounds__(1024) void k_gn_stats(const f16 *__restrict__ x, int HW, int C, int G, int NS, int PL,
+template <bool X32>
+__global__ __launch_bounds__(1024) void k_gn_stats(const void *__restrict__ x, int HW, int C, int G, int NS, int PL,
                                                    float *__restrict__ part)
 {
     extern __shared__ float s_part[];          // [PL][C][2]
@@ -33,17 +52,16 @@ __global__ __launch_bounds__(1024) void k_gn_stats(const f16 *__restrict__ x, in
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-    const f16 *base = x + ((size_t)b * HW) * C + c8 * 8;
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t base = ((size_t)b * HW) * C + c8 * 8;
     for (int p = p0 + pl; p < p1; p += PL * GN_U) {
-        f16x8 v[GN_U];
+        F8 v[GN_U];
 #pragma unroll
-        for (int u = 0; u < GN_U; ++u) v[u] = *(const f16x8 *)(base + (size_t)min(p + u * PL, p1 - 1) * C);   // unconditional
+        for (int u = 0; u < GN_U; ++u) v[u] = ld8<X32>(x, base + (size_t)min(p + u * PL, p1 - 1) * C);   // unconditional
 #pragma unroll
         for (int u = 0; u < GN_U; ++u) {
-            if (p + u * PL >= p1) v[u] = zero8;
+            const bool live = p + u * PL < p1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
+            for (int j = 0; j < 8; ++j) { float f = live ? v[u].v[j] : 0.f; s[j] += f; q[j] += f * f; }
         }
     }
 #pragma unroll
@@ -89,7 +107,8 @@ __global__ __launch_bounds__(1024) void k_gn_stats(const f16 *__restrict__ x, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, const float *__restrict__ part,
+template <bool X32>
+__global__ __launch_bounds__(256) void k_gn_apply(const void *__restrict__ x, const float *__restrict__ part,
                                                   const f16 *__restrict__ gamma, const f16 *__restrict__ beta, int HW, int C,
                                                   int G, int NS, float eps, int silu, f16 *__restrict__ y)
 {
@@ -97,16 +116,16 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
     __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
     const int b = blockIdx.y;
     const int c8n = C / 8;
-    const f16 *xb = x + (size_t)b * HW * C;
+    const size_t xb = (size_t)b * HW * C;
     f16 *yb = y + (size_t)b * HW * C;
     const unsigned total = (unsigned)HW * (unsigned)c8n;
     // a block owns a contiguous run of 16-byte chunks and walks it in batches of GN_AU x 256
     const unsigned per = ((total + gridDim.x - 1) / gridDim.x + 255u) & ~255u;
     const unsigned beg = blockIdx.x * per, end = min(total, beg + per);
-    f16x8 v[GN_AU];
+    F8 v[GN_AU];
 #pragma unroll
     for (int u = 0; u < GN_AU; ++u)                                         // first batch: in flight during the fold below
-        v[u] = *(const f16x8 *)(xb + (size_t)min(beg + 256u * u + threadIdx.x, total - 1u) * 8);
+        v[u] = ld8<X32>(x, xb + (size_t)min(beg + 256u * u + threadIdx.x, total - 1u) * 8);
     // gamma / beta go to LDS now (their latency overlaps the partial loads below instead of following the barrier)
     for (int c = threadIdx.x; c < C; c += 256) {
         s_ab[c] = (float)gamma[c];
@@ -144,11 +163,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
     }
     __syncthreads();
     for (unsigned i0 = beg; i0 < end; i0 += 256u * GN_AU) {
-        f16x8 nx[GN_AU];
+        F8 nx[GN_AU];
         const unsigned n0 = i0 + 256u * GN_AU;
         if (n0 < end) {
 #pragma unroll
-            for (int u = 0; u < GN_AU; ++u) nx[u] = *(const f16x8 *)(xb + (size_t)min(n0 + 256u * u + threadIdx.x, total - 1u) * 8);
+            for (int u = 0; u < GN_AU; ++u) nx[u] = ld8<X32>(x, xb + (size_t)min(n0 + 256u * u + threadIdx.x, total - 1u) * 8);
         }
 #pragma unroll
         for (int u = 0; u < GN_AU; ++u) {
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
                 f32x4 b0 = *(const f32x4 *)(s_ab + C + c0), b1 = *(const f32x4 *)(s_ab + C + c0 + 4);
                 float f[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { f[j] = (float)v[u][j] * a0[j] + b0[j]; f[4 + j] = (float)v[u][4 + j] * a1[j] + b1[j]; }
+                for (int j = 0; j < 4; ++j) { f[j] = v[u].v[j] * a0[j] + b0[j]; f[4 + j] = v[u].v[4 + j] * a1[j] + b1[j]; }
                 f16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -183,7 +202,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const f16 *__restrict__ x, con
 // At the UNet's two deepest levels this replaces two latency-bound launches and one re-read of the tensor.
 #define GN_FT 512
 #define GN_FU 12
-__global__ __launch_bounds__(GN_FT) void k_gn_fused(const f16 *__restrict__ x, const f16 *__restrict__ gamma,
+template <bool X32>
+__global__ __launch_bounds__(GN_FT) void k_gn_fused(const void *__restrict__ x, const f16 *__restrict__ gamma,
                                                     const f16 *__restrict__ beta, int HW, int C, int G, float eps, int silu,
                                                     f16 *__restrict__ y)
 {
@@ -192,24 +212,24 @@ __global__ __launch_bounds__(GN_FT) void k_gn_fused(const f16 *__restrict__ x, c
     const int g = blockIdx.x, b = blockIdx.y;
     const int cg = C / G, cpg = cg / 8;                // chunks per pixel in this group
     const int total = HW * cpg;
-    const f16 *xb = x + (size_t)b * HW * C + g * cg;
+    const size_t xb = (size_t)b * HW * C + g * cg;
     f16 *yb = y + (size_t)b * HW * C + g * cg;
     for (int c = threadIdx.x; c < cg; c += GN_FT) { s_gb[0][c] = (float)gamma[g * cg + c]; s_gb[1][c] = (float)beta[g * cg + c]; }
-    f16x8 v[GN_FU];
+    F8 v[GN_FU];
     int off[GN_FU];
 #pragma unroll
     for (int u = 0; u < GN_FU; ++u) {
         const int i = min((int)threadIdx.x + GN_FT * u, total - 1);
         const int p = i / cpg, c = i - p * cpg;
         off[u] = p * C + c * 8;
-        v[u] = *(const f16x8 *)(xb + off[u]);          // unconditional (clamped), all in flight
+        v[u] = ld8<X32>(x, xb + off[u]);               // unconditional (clamped), all in flight
     }
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int u = 0; u < GN_FU; ++u)
         if ((int)threadIdx.x + GN_FT * u < total) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { float f = (float)v[u][j]; s += f; q += f * f; }
+            for (int j = 0; j < 8; ++j) { float f = v[u].v[j]; s += f; q += f * f; }
         }
     s = wave_sum_dpp(s); q = wave_sum_dpp(q);
     const int wave = threadIdx.x >> 6;
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(GN_FT) void k_gn_fused(const f16 *__restrict__ x, c
             f16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float t = ((float)v[u][j] - mean) * rstd * s_gb[0][c0 + j] + s_gb[1][c0 + j];
+                float t = (v[u].v[j] - mean) * rstd * s_gb[0][c0 + j] + s_gb[1][c0 + j];
                 if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
                 o[j] = (f16)t;
             }
@@ -246,18 +266,25 @@ extern "C" int64_t ctx_groupnorm_ws_bytes(int32_t B, int32_t groups)
 extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const void *beta, int32_t B, int32_t HW, int32_t C,
                                      int32_t groups, float eps, int32_t silu, void *y, void *stats_ws, ctx_stream_t stream)
 {
+    return ctx_groupnorm_any(x, 0, gamma, beta, B, HW, C, groups, eps, silu, y, stats_ws, (hipStream_t)stream);
+}
+
+// x32 != 0: the input is the fp32 residual stream (the output stays fp16: it is the next GEMM's operand)
+int ctx_groupnorm_any(const void *x, int x32, const void *gamma, const void *beta, int B, int HW, int C, int groups, float eps, int silu,
+                      void *y, void *stats_ws, hipStream_t stream)
+{
     CTX_REQUIRE(x && gamma && beta && y && stats_ws, "groupnorm: null pointer");
     CTX_REQUIRE(B > 0 && HW > 0 && C % 8 == 0 && C % groups == 0 && groups <= GN_MAX_GROUPS && C <= GN_MAX_C &&
                     256 % groups == 0 && (256 / groups & (256 / groups - 1)) == 0,
                 "groupnorm: unsupported B=%d HW=%d C=%d groups=%d", B, HW, C, groups);
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = stream;
     {
         static int fuse = -1;
         if (fuse < 0) { const char *e = getenv("CTX_GN_FUSED"); fuse = e ? atoi(e) : 1; }
         const int cg = C / groups;
         if (fuse && cg % 8 == 0 && cg <= GN_MAX_C / 16 && (int64_t)HW * (cg / 8) <= GN_FT * GN_FU) {
-            hipLaunchKernelGGL(k_gn_fused, dim3(groups, B), dim3(GN_FT), 0, s, (const f16 *)x, (const f16 *)gamma, (const f16 *)beta, HW, C,
-                               groups, eps, silu, (f16 *)y);
+            if (x32) hipLaunchKernelGGL(k_gn_fused<true>, dim3(groups, B), dim3(GN_FT), 0, s, x, (const f16 *)gamma, (const f16 *)beta, HW, C, groups, eps, silu, (f16 *)y);
+            else hipLaunchKernelGGL(k_gn_fused<false>, dim3(groups, B), dim3(GN_FT), 0, s, x, (const f16 *)gamma, (const f16 *)beta, HW, C, groups, eps, silu, (f16 *)y);
             CTX_CHECK_LAUNCH("groupnorm");
             return CTX_OK;
         }
@@ -272,16 +299,23 @@ extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const voi
     const int na = threads / C > 1 ? threads / C : 1;
     size_t lds = (size_t)(PL + na) * C * 2 * sizeof(float);   // <= 72 KiB (threads <= 1024, 8 channels each)
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_gn_stats, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }
-    hipLaunchKernelGGL(k_gn_stats, dim3(NS, B), dim3(threads), lds, s, (const f16 *)x, HW, C, groups, NS, PL, part);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)k_gn_stats<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_gn_stats<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr = true;
+    }
+    if (x32) hipLaunchKernelGGL(k_gn_stats<true>, dim3(NS, B), dim3(threads), lds, s, x, HW, C, groups, NS, PL, part);
+    else hipLaunchKernelGGL(k_gn_stats<false>, dim3(NS, B), dim3(threads), lds, s, x, HW, C, groups, NS, PL, part);
     size_t total = (size_t)HW * c8n;
     // fat blocks (the per-block fold of the split partials is amortised), at least one batch each
     int nb = (int)((total + 256 * GN_AU - 1) / (256 * GN_AU));
     static const int cap_env = [] { const char *e = getenv("CTX_GN_APPLY_CAP"); return e ? atoi(e) : 0; }();
     const int cap = cap_env > 0 ? cap_env : (B >= 2 ? 128 : 256);   // ~one block per CU: the per-block fold of the partials is not free
     if (nb > cap) nb = cap;
-    hipLaunchKernelGGL(k_gn_apply, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, (const f16 *)x, part, (const f16 *)gamma,
-                       (const f16 *)beta, HW, C, groups, NS, eps, silu, (f16 *)y);
+    if (x32) hipLaunchKernelGGL(k_gn_apply<true>, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, x, part, (const f16 *)gamma,
+                                (const f16 *)beta, HW, C, groups, NS, eps, silu, (f16 *)y);
+    else hipLaunchKernelGGL(k_gn_apply<false>, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, x, part, (const f16 *)gamma,
+                            (const f16 *)beta, HW, C, groups, NS, eps, silu, (f16 *)y);
     CTX_CHECK_LAUNCH("groupnorm");
     return CTX_OK;
 }
@@ -289,8 +323,8 @@ extern "C" int32_t ctx_groupnorm_f16(const void *x, const void *gamma, const voi
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wave per LN_R rows at a time, up to 4 x 16-byte chunks per lane per row
 // (C <= 2048); all LN_R rows' loads are issued before the first reduction.
-template <int KC, int R>
-__global__ __launch_bounds__(256) void k_layernorm(const f16 *__restrict__ x, const f16 *__restrict__ gamma,
+template <int KC, int R, bool X32>
+__global__ __launch_bounds__(256) void k_layernorm(const void *__restrict__ x, const f16 *__restrict__ gamma,
                                                    const f16 *__restrict__ beta, int64_t rows, int C, float eps,
                                                    f16 *__restrict__ y)
 {
@@ -299,16 +333,18 @@ __global__ __launch_bounds__(256) void k_layernorm(const f16 *__restrict__ x, co
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t row0 = wave * R;
     if (row0 >= rows) return;
-    f16x8 v[R][KC];
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    F8 v[R][KC];
 #pragma unroll
     for (int rr = 0; rr < R; ++rr)
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             int c8 = lane + 64 * k;
             const int64_t rw = row0 + rr < rows ? row0 + rr : rows - 1;
-            v[rr][k] = *(const f16x8 *)(x + rw * C + min(c8, c8n - 1) * 8);          // unconditional load, masked below
-            if (c8 >= c8n) v[rr][k] = zero8;
+            v[rr][k] = ld8<X32>(x, (size_t)(rw * C + min(c8, c8n - 1) * 8));          // unconditional load, masked below
+            if (c8 >= c8n) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[rr][k].v[j] = 0.f;
+            }
         }
     f16x8 ga[KC], be[KC];
 #pragma unroll
@@ -324,7 +360,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const f16 *__restrict__ x, co
 #pragma unroll
         for (int k = 0; k < KC; ++k)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)v[rr][k][j];            // padded lanes hold zeros
+            for (int j = 0; j < 8; ++j) s += v[rr][k].v[j];                 // padded lanes hold zeros
         float mean = wave_sum_dpp(s) / (float)C;
         float q = 0.f;
 #pragma unroll
@@ -332,7 +368,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const f16 *__restrict__ x, co
             int c8 = lane + 64 * k;
             if (c8 < c8n) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { float d = (float)v[rr][k][j] - mean; q += d * d; }
+                for (int j = 0; j < 8; ++j) { float d = v[rr][k].v[j] - mean; q += d * d; }
             }
         }
         float rstd = rsqrtf(wave_sum_dpp(q) / (float)C + eps);
@@ -343,7 +379,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const f16 *__restrict__ x, co
             if (c8 < c8n) {
                 f16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)v[rr][k][j] - mean) * rstd * (float)ga[k][j] + (float)be[k][j]);
+                for (int j = 0; j < 8; ++j) o[j] = (f16)((v[rr][k].v[j] - mean) * rstd * (float)ga[k][j] + (float)be[k][j]);
                 *(f16x8 *)(yr + c8 * 8) = o;
             }
         }
@@ -353,10 +389,17 @@ __global__ __launch_bounds__(256) void k_layernorm(const f16 *__restrict__ x, co
 extern "C" int32_t ctx_layernorm_f16(const void *x, const void *gamma, const void *beta, int64_t rows, int32_t C, float eps,
                                      void *y, ctx_stream_t stream)
 {
+    return ctx_layernorm_any(x, 0, gamma, beta, rows, C, eps, y, (hipStream_t)stream);
+}
+
+int ctx_layernorm_any(const void *x, int x32, const void *gamma, const void *beta, int64_t rows, int C, float eps, void *y, hipStream_t stream)
+{
     CTX_REQUIRE(x && gamma && beta && y && rows > 0 && C % 8 == 0 && C <= 2048, "layernorm: unsupported rows=%lld C=%d", (long long)rows, C);
     const int kc = (C / 8 + 63) / 64;                          // 16-byte chunks per lane per row
 #define LN_GO(KC_, R_) do { int64_t nb = cdiv64(cdiv64(rows, R_), 4); \
-        hipLaunchKernelGGL((k_layernorm<KC_, R_>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const f16 *)x, \
+        if (x32) hipLaunchKernelGGL((k_layernorm<KC_, R_, true>), dim3((unsigned)nb), dim3(256), 0, stream, x, \
+                           (const f16 *)gamma, (const f16 *)beta, rows, C, eps, (f16 *)y); \
+        else hipLaunchKernelGGL((k_layernorm<KC_, R_, false>), dim3((unsigned)nb), dim3(256), 0, stream, x, \
                            (const f16 *)gamma, (const f16 *)beta, rows, C, eps, (f16 *)y); } while (0)
     // rows per wave: ~4 loads in flight per lane, but keep >= ~2 waves per SIMD of work on the chip
     const bool many = rows >= 8192;
@@ -414,6 +457,12 @@ __global__ __launch_bounds__(256) void k_concat(const f16 *__restrict__ a, const
     }
 }
 
+// same copy with 4-byte elements (the fp32 residual stream): channels counted in f16-equivalents of 2 x the float count
+int ctx_concat_f32(const float *a, const float *b, int64_t M, int Ca, int Cb, float *y, hipStream_t s)
+{
+    return ctx_concat_f16((const f16 *)a, (const f16 *)b, M, 2 * Ca, 2 * Cb, (f16 *)y, s);
+}
+
 int ctx_concat_f16(const f16 *a, const f16 *b, int64_t M, int Ca, int Cb, f16 *y, hipStream_t s)
 {
     int64_t nb = cdiv64(M * ((Ca + Cb) / 8), 256);
@@ -459,6 +508,21 @@ int ctx_transpose_v_f16(const f16 *v, int B, int S, int ld, int heads, int Sp, i
 __global__ __launch_bounds__(256) void k_f32_to_f16(const float *__restrict__ x, int64_t n, f16 *__restrict__ y)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (f16)x[i];
+}
+__global__ __launch_bounds__(256) void k_f16_to_f32(const f16 *__restrict__ x, int64_t n8, float *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f16x8 v = *(const f16x8 *)(x + i * 8);
+        f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+        *(f32x4 *)(y + i * 8) = a; *(f32x4 *)(y + i * 8 + 4) = b;
+    }
+}
+int ctx_f16_to_f32(const f16 *x, int64_t n, float *y, hipStream_t s)
+{
+    int64_t nb = cdiv64(n / 8, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_f16_to_f32, dim3((unsigned)nb), dim3(256), 0, s, x, n / 8, y);
+    return CTX_OK;
 }
 int ctx_f32_to_f16(const float *x, int64_t n, f16 *y, hipStream_t s)
 {

@@ -92,6 +92,10 @@ struct ctx_unet {
     // main UNet pass: residuals to add (same layout) and their scale
     const f16 *add_res = nullptr;
     float add_scale = 1.0f;
+    // experiment: keep the residual stream — every tensor that is the sum of a block's input and its
+    // branch, and the skip copies of those — in fp32; GEMM / conv operands stay fp16 (cast on the way in), accumulators fp32
+    bool res32 = false;
+    void *allocS(size_t n) { return alloc(n * (res32 ? 4 : 2)); }          // a residual-stream tensor of n elements
 
     size_t walloc(size_t n) { size_t o = wtop; wtop += (n + 127) / 128 * 128; return o; }
     size_t add(const std::string &name, std::vector<int64_t> shp, int kind, size_t dst, int a = 0, int b = 0)
@@ -452,12 +456,14 @@ __global__ __launch_bounds__(256) void k_add_scaled_f16(f16 *__restrict__ dst, c
 static void note(ctx_unet *u, int klass, double fl, int n = 1) { u->launches[klass] += n; u->flops[klass] += fl; }
 #define RUN(expr) do { if (!u->dry && u->rc == 0) { int r__ = (expr); if (r__ != 0) u->rc = r__; } } while (0)
 
-static void op_gemm(ctx_unet *u, const f16 *X, size_t w, size_t bias, bool has_bias, const f16 *res, int M, int N, int K, f16 *out,
-                    int epi = 0)
+// res / out are residual-stream tensors (fp32 when u->res32) iff res_s / out_s
+static void op_gemm(ctx_unet *u, const f16 *X, size_t w, size_t bias, bool has_bias, const void *res, int M, int N, int K, void *out,
+                    int epi = 0, bool res_s = false, bool out_s = false)
 {
     GemmArgs a = {};
-    a.X = X; a.Wt = u->W + w; a.bias = has_bias ? u->W + bias : nullptr; a.residual = res; a.out = out;
+    a.X = X; a.Wt = u->W + w; a.bias = has_bias ? u->W + bias : nullptr; a.residual = (const f16 *)res; a.out = (f16 *)out;
     a.M = M; a.N = N; a.K = K; a.ldc = epi == 1 ? N / 2 : N; a.ldr = N; a.rows_per_batch = 1; a.ldrb = N; a.epi = epi;
+    a.res32 = (u->res32 && res_s && res) ? 1 : 0; a.out32 = (u->res32 && out_s) ? 1 : 0;
     note(u, 0, 2.0 * M * N * K);
     size_t mark = u->top;
     ctx_gemm_plan(a, false);
@@ -465,15 +471,16 @@ static void op_gemm(ctx_unet *u, const f16 *X, size_t w, size_t bias, bool has_b
     RUN(ctx_gemm_dispatch(a, false, u->s));
     u->top = mark;
 }
-static void op_conv(ctx_unet *u, const f16 *x, size_t w, size_t bias, const f16 *rowbias, int ldrb, const f16 *res, int B, int H,
-                    int W, int Cin, int Cout, int stride, int ups, f16 *out)
+static void op_conv(ctx_unet *u, const f16 *x, size_t w, size_t bias, const f16 *rowbias, int ldrb, const void *res, int B, int H,
+                    int W, int Cin, int Cout, int stride, int ups, void *out, bool res_s = false, bool out_s = false)
 {
     GemmArgs a = {};
     int Hv = H << ups, Wv = W << ups;
     a.Ho = (Hv - 1) / stride + 1; a.Wo = (Wv - 1) / stride + 1;
-    a.X = x; a.Wt = u->W + w; a.bias = u->W + bias; a.rowbias = rowbias; a.residual = res; a.out = out;
+    a.X = x; a.Wt = u->W + w; a.bias = u->W + bias; a.rowbias = rowbias; a.residual = (const f16 *)res; a.out = (f16 *)out;
     a.M = B * a.Ho * a.Wo; a.N = Cout; a.K = 9 * Cin; a.ldc = Cout; a.ldr = Cout; a.rows_per_batch = a.Ho * a.Wo; a.ldrb = ldrb;
     a.H = H; a.W = W; a.Cin = Cin; a.stride = stride; a.ups = ups;
+    a.res32 = (u->res32 && res_s && res) ? 1 : 0; a.out32 = (u->res32 && out_s) ? 1 : 0;
     note(u, 0, 2.0 * a.M * a.N * a.K);
     size_t mark = u->top;
     ctx_gemm_plan(a, true);
@@ -481,15 +488,25 @@ static void op_conv(ctx_unet *u, const f16 *x, size_t w, size_t bias, const f16 
     RUN(ctx_gemm_dispatch(a, true, u->s));
     u->top = mark;
 }
-static void op_gn(ctx_unet *u, const f16 *x, size_t g, size_t b, int B, int HW, int C, float eps, int silu, f16 *y, void *stats)
+// x_s: x is a residual-stream tensor
+static void op_gn(ctx_unet *u, const void *x, size_t g, size_t b, int B, int HW, int C, float eps, int silu, f16 *y, void *stats, bool x_s = true)
 {
     note(u, 2, 0, 2);
-    RUN(ctx_groupnorm_f16(x, u->W + g, u->W + b, B, HW, C, u->cfg.groups, eps, silu, y, stats, u->s));
+    RUN(ctx_groupnorm_any(x, (u->res32 && x_s) ? 1 : 0, u->W + g, u->W + b, B, HW, C, u->cfg.groups, eps, silu, y, stats, u->s));
 }
-static void op_ln(ctx_unet *u, const f16 *x, size_t g, size_t b, int64_t rows, int C, f16 *y)
+static void op_ln(ctx_unet *u, const void *x, size_t g, size_t b, int64_t rows, int C, f16 *y)
 {
     note(u, 2, 0);
-    RUN(ctx_layernorm_f16(x, u->W + g, u->W + b, rows, C, 1e-5f, y, u->s));
+    RUN(ctx_layernorm_any(x, u->res32 ? 1 : 0, u->W + g, u->W + b, rows, C, 1e-5f, y, u->s));
+}
+// fp16 GEMM / conv operand of a residual-stream tensor: the tensor itself, or (res32) a rounded copy above the arena mark
+static const f16 *op_as16(ctx_unet *u, const void *x, size_t n)
+{
+    if (!u->res32) return (const f16 *)x;
+    f16 *c = u->allocH(n);
+    note(u, 2, 0);
+    RUN(ctx_f32_to_f16((const float *)x, (int64_t)n, c, u->s));
+    return c;
 }
 static void op_attn(ctx_unet *u, const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, int Skv, int heads, int qs, int kvs, f16 *O)
 {
@@ -505,7 +522,7 @@ struct FwdCtx {
     void *gn_stats;
 };
 
-static f16 *run_resnet(ctx_unet *u, const FwdCtx &f, const ResP &r, const f16 *x, int H, int W, f16 *out)
+static void *run_resnet(ctx_unet *u, const FwdCtx &f, const ResP &r, const void *x, int H, int W, void *out)
 {
     const int B = f.B, HW = H * W, M = B * HW;
     size_t mark = u->top;
@@ -514,26 +531,26 @@ static f16 *run_resnet(ctx_unet *u, const FwdCtx &f, const ResP &r, const f16 *x
     f16 *h = u->allocH((size_t)M * r.cout);
     op_conv(u, t1, r.c1w, r.c1b, f.tproj ? f.tproj + r.temb_row : nullptr, u->temb_rows, nullptr, B, H, W, r.cin, r.cout, 1, 0, h);
     f16 *t2 = u->allocH((size_t)M * r.cout);
-    op_gn(u, h, r.n2g, r.n2b, B, HW, r.cout, u->cfg.norm_eps, 1, t2, f.gn_stats);
-    const f16 *sc = x;
+    op_gn(u, h, r.n2g, r.n2b, B, HW, r.cout, u->cfg.norm_eps, 1, t2, f.gn_stats, false);
+    const void *sc = x;
     if (r.cin != r.cout) {
-        f16 *s2 = u->allocH((size_t)M * r.cout);
-        op_gemm(u, x, r.scw, r.scb, true, nullptr, M, r.cout, r.cin, s2);
+        void *s2 = u->allocS((size_t)M * r.cout);
+        op_gemm(u, op_as16(u, x, (size_t)M * r.cin), r.scw, r.scb, true, nullptr, M, r.cout, r.cin, s2, 0, false, true);
         sc = s2;
     }
-    op_conv(u, t2, r.c2w, r.c2b, nullptr, 0, sc, B, H, W, r.cout, r.cout, 1, 0, out);
+    op_conv(u, t2, r.c2w, r.c2b, nullptr, 0, sc, B, H, W, r.cout, r.cout, 1, 0, out, true, true);
     u->top = mark;
     return out;
 }
 
-static f16 *run_transformer(ctx_unet *u, const FwdCtx &f, const TrP &t, const f16 *x, int H, int W, f16 *out)
+static void *run_transformer(ctx_unet *u, const FwdCtx &f, const TrP &t, const void *x, int H, int W, void *out)
 {
     const int B = f.B, S = H * W, M = B * S, C = t.C, cd = u->cfg.cross_attention_dim;
     size_t mark = u->top;
     f16 *g = u->allocH((size_t)M * C);
     op_gn(u, x, t.ng, t.nb, B, S, C, 1e-6f, 0, g, f.gn_stats);
-    f16 *h0 = u->allocH((size_t)M * C);
-    op_gemm(u, g, t.piw, t.pib, true, nullptr, M, C, C, h0);
+    void *h0 = u->allocS((size_t)M * C);
+    op_gemm(u, g, t.piw, t.pib, true, nullptr, M, C, C, h0, 0, false, true);
     // self attention
     f16 *l = g;   // reuse
     op_ln(u, h0, t.l1g, t.l1b, M, C, l);
@@ -574,8 +591,8 @@ static f16 *run_transformer(ctx_unet *u, const FwdCtx &f, const TrP &t, const f1
         a = u->allocH((size_t)M * C);
         op_attn(u, qkv, qkv + C, qkv + 2 * C, B, S, S, t.heads, 3 * C, 3 * C, a);
     }
-    f16 *h1 = u->allocH((size_t)M * C);
-    op_gemm(u, a, t.o1w, t.o1b, true, h0, M, C, C, h1);
+    void *h1 = u->allocS((size_t)M * C);
+    op_gemm(u, a, t.o1w, t.o1b, true, h0, M, C, C, h1, 0, true, true);
     // cross attention
     op_ln(u, h1, t.l2g, t.l2b, M, C, l);
     f16 *q = a;   // reuse
@@ -583,15 +600,15 @@ static f16 *run_transformer(ctx_unet *u, const FwdCtx &f, const TrP &t, const f1
     const f16 *kv = f.kv_all + t.kv_row;
     f16 *a2 = u->allocH((size_t)M * C);
     op_attn(u, q, kv, kv + C, B, S, f.L, t.heads, C, u->kv_rows_total, a2);
-    f16 *h2 = h0;  // h0 is dead after h1 was produced
-    op_gemm(u, a2, t.o2w, t.o2b, true, h1, M, C, C, h2);
+    void *h2 = h0;  // h0 is dead after h1 was produced
+    op_gemm(u, a2, t.o2w, t.o2b, true, h1, M, C, C, h2, 0, true, true);
     // feed forward (GEGLU fused into the first GEMM's epilogue)
     op_ln(u, h2, t.l3g, t.l3b, M, C, l);
     f16 *ff = u->allocH((size_t)M * 4 * C);
     op_gemm(u, l, t.f1w, t.f1b, true, nullptr, M, 8 * C, C, ff, 1);
-    f16 *h3 = h1;
-    op_gemm(u, ff, t.f2w, t.f2b, true, h2, M, C, 4 * C, h3);
-    op_gemm(u, h3, t.pow_, t.pob, true, x, M, C, C, out);
+    void *h3 = h1;
+    op_gemm(u, ff, t.f2w, t.f2b, true, h2, M, C, 4 * C, h3, 0, true, true);
+    op_gemm(u, op_as16(u, h3, (size_t)M * C), t.pow_, t.pob, true, x, M, C, C, out, 0, true, true);
     u->top = mark;
     return out;
 }
@@ -626,8 +643,17 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
     f.kv_all = kv_all;
 
     int h = H, w = W;
-    f16 *x = u->allocH((size_t)B * h * w * ch[0]);
-    note(u, 2, 2.0 * B * h * w * ch[0] * c.in_channels * 9); RUN(ctx_conv_in_f16(sample, u->W + u->ciw, u->W + u->cib, B, c.in_channels, h, w, ch[0], x, u->s));
+    if (u->res32 && (u->is_controlnet || u->add_res || u->ref_mode)) {
+        ctx_set_error("unet: the fp32 residual-stream mode covers the plain UNet forward only");
+        return CTX_E_STATE;
+    }
+    void *x = u->allocS((size_t)B * h * w * ch[0]);
+    {
+        size_t m0 = u->top;
+        f16 *x16 = u->res32 ? u->allocH((size_t)B * h * w * ch[0]) : (f16 *)x;
+        note(u, 2, 2.0 * B * h * w * ch[0] * c.in_channels * 9); RUN(ctx_conv_in_f16(sample, u->W + u->ciw, u->W + u->cib, B, c.in_channels, h, w, ch[0], x16, u->s));
+        if (u->res32) { note(u, 2, 0); RUN(ctx_f16_to_f32(x16, (int64_t)B * h * w * ch[0], (float *)x, u->s)); u->top = m0; }
+    }
 
     auto add_scaled = [&](f16 *dst, const f16 *src, float scale, size_t n) {
         note(u, 2, 0);
@@ -663,7 +689,7 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
         if (!u->dry && u->rc == 0) (void)hipMemcpyAsync(x, emb, (size_t)B * h * w * ch[0] * 2, hipMemcpyDeviceToDevice, u->s);
         u->top = mark;
     }
-    struct Skip { f16 *p; int C, h, w; };
+    struct Skip { void *p; int C, h, w; };
     std::vector<Skip> skips;
     skips.push_back({x, ch[0], h, w});
     int cur = ch[0];
@@ -671,10 +697,10 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
         LevelP &Lv = u->down[i];
         for (int j = 0; j < lpb; ++j) {
             int cout = Lv.res[j].cout;
-            f16 *o = u->allocH((size_t)B * h * w * cout);
+            void *o = u->allocS((size_t)B * h * w * cout);
             if (Lv.has_attn) {
                 size_t mark = u->top;
-                f16 *t = u->allocH((size_t)B * h * w * cout);
+                void *t = u->allocS((size_t)B * h * w * cout);
                 run_resnet(u, f, Lv.res[j], x, h, w, t);
                 run_transformer(u, f, Lv.tr[j], t, h, w, o);
                 u->top = mark;
@@ -684,8 +710,10 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
         }
         if (Lv.has_sampler) {
             int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
-            f16 *o = u->allocH((size_t)B * ho * wo * cur);
-            op_conv(u, x, Lv.sw, Lv.sb, nullptr, 0, nullptr, B, h, w, cur, cur, 2, 0, o);
+            void *o = u->allocS((size_t)B * ho * wo * cur);
+            size_t m0 = u->top;
+            op_conv(u, op_as16(u, x, (size_t)B * h * w * cur), Lv.sw, Lv.sb, nullptr, 0, nullptr, B, h, w, cur, cur, 2, 0, o, false, true);
+            u->top = m0;
             x = o; h = ho; w = wo;
             skips.push_back({x, cur, h, w});
         }
@@ -697,7 +725,7 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
         for (size_t k = 0; k < skips.size(); ++k) {
             const Skip &sk = skips[k];
             const size_t nel = (size_t)B * sk.h * sk.w * sk.C;
-            op_gemm(u, sk.p, u->zc_w[k], u->zc_b[k], true, nullptr, B * sk.h * sk.w, sk.C, sk.C, u->cn_out ? u->cn_out + res_off : nullptr);
+            op_gemm(u, (const f16 *)sk.p, u->zc_w[k], u->zc_b[k], true, nullptr, B * sk.h * sk.w, sk.C, sk.C, u->cn_out ? u->cn_out + res_off : nullptr);
             res_off += nel;
         }
     } else if (u->add_res) {
@@ -710,21 +738,21 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
                 if (!u->dry && u->rc == 0) (void)hipMemcpyAsync(cp, sk.p, nel * 2, hipMemcpyDeviceToDevice, u->s);
                 sk.p = cp;
             }
-            add_scaled(sk.p, u->add_res + res_off, u->add_scale, nel);
+            add_scaled((f16 *)sk.p, u->add_res + res_off, u->add_scale, nel);
             res_off += nel;
         }
     }
     {
-        f16 *o1 = u->allocH((size_t)B * h * w * cur);
+        void *o1 = u->allocS((size_t)B * h * w * cur);
         run_resnet(u, f, u->mid.res[0], x, h, w, o1);
-        f16 *o2 = u->allocH((size_t)B * h * w * cur);
+        void *o2 = u->allocS((size_t)B * h * w * cur);
         run_transformer(u, f, u->mid.tr[0], o1, h, w, o2);
-        f16 *o3 = o1 == x ? u->allocH((size_t)B * h * w * cur) : u->allocH((size_t)B * h * w * cur);
+        void *o3 = u->allocS((size_t)B * h * w * cur);
         run_resnet(u, f, u->mid.res[1], o2, h, w, o3);
         x = o3;
     }
     if (u->is_controlnet) {
-        op_gemm(u, x, u->zm_w, u->zm_b, true, nullptr, B * h * w, cur, cur, u->cn_out ? u->cn_out + res_off : nullptr);
+        op_gemm(u, (const f16 *)x, u->zm_w, u->zm_b, true, nullptr, B * h * w, cur, cur, u->cn_out ? u->cn_out + res_off : nullptr);
         res_off += (size_t)B * h * w * cur;
         u->ref_cursor = res_off;               // element count of the residual buffer (read by the size query)
         if (!u->dry && u->rc == 0) {
@@ -733,19 +761,21 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
         }
         return u->rc;
     }
-    if (u->add_res) add_scaled(x, u->add_res + res_off, u->add_scale, (size_t)B * h * w * cur);
+    if (u->add_res) add_scaled((f16 *)x, u->add_res + res_off, u->add_scale, (size_t)B * h * w * cur);
     for (int i = 0; i < n; ++i) {
         LevelP &Lv = u->up[i];
         for (int j = 0; j <= lpb; ++j) {
             Skip sk = skips.back(); skips.pop_back();
             if (sk.h != h || sk.w != w) { ctx_set_error("unet: skip size mismatch (H, W must be multiples of %d)", 1 << (n - 1)); return CTX_E_ARG; }
             int cin = cur + sk.C, cout = Lv.res[j].cout;
-            f16 *o = u->allocH((size_t)B * h * w * cout);
+            void *o = u->allocS((size_t)B * h * w * cout);
             size_t mark = u->top;
-            f16 *cat = u->allocH((size_t)B * h * w * cin);
-            note(u, 2, 0); RUN(ctx_concat_f16(x, sk.p, (int64_t)B * h * w, cur, sk.C, cat, u->s));
+            void *cat = u->allocS((size_t)B * h * w * cin);
+            note(u, 2, 0);
+            if (u->res32) RUN(ctx_concat_f32((const float *)x, (const float *)sk.p, (int64_t)B * h * w, cur, sk.C, (float *)cat, u->s));
+            else RUN(ctx_concat_f16((const f16 *)x, (const f16 *)sk.p, (int64_t)B * h * w, cur, sk.C, (f16 *)cat, u->s));
             if (Lv.has_attn) {
-                f16 *t = u->allocH((size_t)B * h * w * cout);
+                void *t = u->allocS((size_t)B * h * w * cout);
                 run_resnet(u, f, Lv.res[j], cat, h, w, t);
                 run_transformer(u, f, Lv.tr[j], t, h, w, o);
             } else run_resnet(u, f, Lv.res[j], cat, h, w, o);
@@ -753,8 +783,10 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
             x = o; cur = cout;
         }
         if (Lv.has_sampler) {
-            f16 *o = u->allocH((size_t)B * (2 * h) * (2 * w) * cur);
-            op_conv(u, x, Lv.sw, Lv.sb, nullptr, 0, nullptr, B, h, w, cur, cur, 1, 1, o);
+            void *o = u->allocS((size_t)B * (2 * h) * (2 * w) * cur);
+            size_t m0 = u->top;
+            op_conv(u, op_as16(u, x, (size_t)B * h * w * cur), Lv.sw, Lv.sb, nullptr, 0, nullptr, B, h, w, cur, cur, 1, 1, o, false, true);
+            u->top = m0;
             x = o; h *= 2; w *= 2;
         }
     }
@@ -886,6 +918,15 @@ extern "C" int32_t ctx_unet_forward_ref(ctx_unet_t *u, const float *sample, cons
     int rc = unet_run(u, sample, timestep, ctx, B, H, W, ctx_len, out);
     u->ref_mode = 0; u->ref_bank = nullptr; u->ref_row0 = 0;
     return rc;
+}
+
+/* Experiment switch: 1 = keep the residual stream (block outputs, skip tensors, the transformer's running
+   sums) in fp32 instead of fp16; GEMM / conv operands and weights stay fp16.  Plain UNet forward only. */
+extern "C" int32_t ctx_unet_set_residual_fp32(ctx_unet_t *u, int32_t on)
+{
+    CTX_REQUIRE(u, "unet_set_residual_fp32: null handle");
+    u->res32 = on != 0;
+    return CTX_OK;
 }
 
 extern "C" int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops)

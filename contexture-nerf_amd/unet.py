@@ -191,6 +191,12 @@ class UNet2DConditionModel:
                 return False
         return _Scope()
 
+    def set_residual_fp32(self, on=True):
+        """Precision experiment: keep the residual stream in fp32 (fp16 operands and weights unchanged)."""
+        L.check(self._lib.ctx_unet_set_residual_fp32(self._h, int(bool(on))))
+        self._ws_key = None
+        return self
+
     def forward_ref(self, sample, timestep, encoder_hidden_states, mode, bank=None, ref_row0=0):
         """Reference-only attention passes (src/zero123plus.py:127-237): mode 'w' parks the attn1 inputs of this forward in a
         bank (returned with the output), mode 'r' appends the parked tokens of `bank` to the self-attention K/V of the batch rows

@@ -220,6 +220,10 @@ int32_t ctx_controlnet_forward(ctx_unet_t *cn, const float *sample, const float 
 int32_t ctx_unet_set_residuals(ctx_unet_t *u, const void *residuals /*nullable*/, float scale);
 /* Per-kernel accounting of the last forward: number of launches and algorithmic FLOPs by class
    (0 gemm/conv MFMA, 1 attention MFMA, 2 other). */
+/* Precision experiment: on != 0 keeps the UNet's residual stream (block outputs, skip tensors, the transformer blocks' running
+   sums) in fp32; operands, weights and everything else stay as they are.  Plain forward only (not the ControlNet / reference-only
+   passes).  The workspace grows: query ctx_unet_workspace_bytes again after switching. */
+int32_t ctx_unet_set_residual_fp32(ctx_unet_t *u, int32_t on);
 int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops);
 
 /* ---- VAE decoder (src/stable_diffusion_depth.py:976-990 decode_latents -> diffusers AutoencoderKL.decode) ---------- */

@@ -707,3 +707,28 @@ def test_vae_encode_backward_vs_oracle(dev, cfgname, B, H, W):
     L, _ = _lib()
     with pytest.raises(CtxError, match="tape"):
         L.check(vae._lib.ctx_vae_encode_bwd(vae._h, L.ptr(cot.to(dev).contiguous()), 1.0, L.ptr(torch.empty_like(xg.grad)), L.stream()))
+
+
+def test_unet_fp32_residual_stream(dev):
+    """The fp32-residual-stream variant (block outputs, skip tensors and the transformer's running sums kept in fp32; operands
+    and weights fp16) against the fp32 oracle, beside the default fp16 stream: small and mid configurations here, the SD2-depth
+    UNet at latent 96 in tools/bench_precision.py (numbers in DESIGN section 7).  The variant must not be worse than the default."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel
+    from oracle import unet_ref
+    for cfg, hw in ((unet_ref.tiny_config(), (16, 16)), (unet_ref.tiny_config(ch=(64, 128, 256, 256), heads=(1, 2, 4, 4), ctx_dim=128), (32, 32))):
+        torch.manual_seed(8)
+        ref = unet_ref.randomize_affine(unet_ref.UNet2DConditionModelRef(cfg)).eval()
+        net = UNet2DConditionModel(cfg, device=dev, init=False); net.load_state_dict(ref.state_dict())
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(2, 5, *hw, generator=g); ctx = torch.randn(2, 11, cfg['cross_attention_dim'], generator=g)
+        with torch.no_grad():
+            want = ref(x, torch.tensor(333.0), ctx)['sample']
+        r16 = _rel(net(x.to(dev), 333.0, ctx.to(dev))['sample'], want)
+        net.set_residual_fp32(True)
+        y32 = net(x.to(dev), 333.0, ctx.to(dev))['sample']
+        r32 = _rel(y32, want)
+        assert torch.equal(y32, net(x.to(dev), 333.0, ctx.to(dev))['sample'])            # deterministic
+        net.set_residual_fp32(False)
+        assert _rel(net(x.to(dev), 333.0, ctx.to(dev))['sample'], want) == r16            # switches back cleanly
+        print(f"residual stream fp16 {r16:.3e} vs fp32 {r32:.3e} (rel L2 vs the fp32 oracle, channels {cfg['block_out_channels']})")
+        assert r32 < 2.5e-3 and r32 <= r16 * 1.05
