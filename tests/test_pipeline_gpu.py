@@ -60,7 +60,7 @@ def test_img2img_denoised_latents_vs_oracle(dev, steps):
                                   image_size=size)
     rel = np.linalg.norm(lat_p.cpu().numpy() - x) / np.linalg.norm(x)
     print(f"img2img {steps} steps: denoised-latent rel L2 vs fp32 oracle = {rel:.3e}")
-    assert rel < 5e-3, rel
+    assert rel < 3e-3, rel                                          # measured 1.6-2.2e-3 (two and six PLMS steps at CFG 10)
     assert rgb.shape == (1, 3, size, size) and torch.isfinite(rgb).all()
     assert torch.equal(rgb, rgb2)                                   # same seed => same result (deterministic kernels)
 
