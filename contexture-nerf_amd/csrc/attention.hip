@@ -118,17 +118,20 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
         }
 }
 
-template <int AT_NS>
-__global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
+// NW waves per workgroup (32 queries each): 4 = 128 queries, 8 = 256 queries per staged K/V tile (half the L2 -> LDS bytes per
+// FLOP: the staging path is this chip's scarce resource, ~28 B/clk per CU, and three 4-wave workgroups per CU ask ~20 of it)
+template <int AT_NS, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) f16 ring[AT_NS * 2 * 64 * 64];    // per stage: K [64][64] then V^T [64][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hd = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
     const int qrow = q0 + r;
     const bool qok = qrow < a.Sq;
-    constexpr int G = 4;                             // DMA pieces per wave per tile (2 K + 2 V^T)
+    constexpr int PI = 8 / NW;                       // K pieces (and V pieces) per wave per tile: the tile is 8 + 8 pieces of 1 KiB
+    constexpr int G = 2 * PI;                        // DMA pieces per wave per tile
 
     f16x8 qf[4];
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -150,11 +153,11 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
     const int ntiles = (a.Skv + AT_KB - 1) / AT_KB;
     // issue-side state: this wave moves pieces {wave, wave+4} of the K tile and of the V^T tile
     const int lr = lane >> 3, pc = lane & 7;
-    const f16 *kp[2], *vp[2];
-    int krow[2];
+    const f16 *kp[PI], *vp[PI];
+    int krow[PI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int row = 8 * (wave + 4 * i) + lr;
+    for (int i = 0; i < PI; ++i) {
+        int row = 8 * (wave + NW * i) + lr;
         int lc = (pc ^ ((row >> 1) & 7)) * 8;
         krow[i] = row;
         kp[i] = a.K + ((size_t)b * a.Skv + row) * a.kv_stride + hd * 64 + lc;
@@ -166,15 +169,15 @@ __global__ __launch_bounds__(256) void k_attention_dma(AttnArgs a)
         f16 *Vs = Ks + 64 * 64;
         const int k0 = issued * AT_KB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PI; ++i) {
             const f16 *src = (k0 + krow[i] < a.Skv) ? kp[i] : g_attn_zero;
-            __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)(Ks + (wave + 4 * i) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)(Ks + (wave + NW * i) * 512), 16, 0, 0);
             kp[i] += (size_t)AT_KB * a.kv_stride;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PI; ++i) {
             const f16 *src = (k0 + krow[i] < a.Skv) ? vp[i] : g_attn_zero;
-            __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)(Vs + (wave + 4 * i) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)(Vs + (wave + NW * i) * 512), 16, 0, 0);
             vp[i] += (size_t)AT_KB * a.kv_stride;
         }
         ++issued;
@@ -231,16 +234,22 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, 
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.Sq = Sq; a.Skv = Skv; a.heads = heads;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
-    static int ns = -1;
+    static int ns = -1, nw8 = -1;
     if (ns < 0) { const char *e = getenv("CTX_ATTN_NS"); ns = e ? atoi(e) : 3; }
-    auto kern = ns == 2 ? k_attention_dma<2> : (ns == 4 ? k_attention_dma<4> : k_attention_dma<3>);
+    // 8-wave workgroups (two per CU at 128 VGPRs) measured against three 4-wave ones (148 VGPRs): 72 vs 77 us at 2304 tokens
+    // x 10 heads, 411 vs 371 us at 9216 x 5 — so only the mid-size self-attention takes them (CTX_ATTN_NW8: 0 never, 1 always)
+    if (nw8 < 0) { const char *e = getenv("CTX_ATTN_NW8"); nw8 = e ? atoi(e) : -1; }
+    const bool w8 = nw8 == 1 || (nw8 < 0 && Sq >= 1024 && Sq < 4096 && Skv >= 1024);
+    auto kern = w8 ? (ns == 2 ? k_attention_dma<2, 8> : (ns == 4 ? k_attention_dma<4, 8> : k_attention_dma<3, 8>))
+                   : (ns == 2 ? k_attention_dma<2, 4> : (ns == 4 ? k_attention_dma<4, 4> : k_attention_dma<3, 4>));
+    const int nthr = w8 ? 512 : 256, qpw = w8 ? 256 : 128;
     static int dbg = -1;
     if (dbg < 0) {
         const char *e = getenv("CTX_ATTN_DEBUG"); dbg = e ? atoi(e) : 0;
         if (dbg) {
             int nb = 0;
             hipFuncAttributes fa;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, nthr, 0);
             (void)hipFuncGetAttributes(&fa, (const void *)kern);
             fprintf(stderr, "[ctx] attention: %d blocks/CU by the occupancy API, %d VGPRs, %zu B static LDS\n", nb, fa.numRegs, fa.sharedSizeBytes);
         }
@@ -248,9 +257,9 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, 
     if (ctx_prof_on()) {
         hipEvent_t e0, e1;
         ctx_prof_events(1, &e0, &e1);
-        hipExtLaunchKernelGGL(kern, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, e0, e1, 0, a);
+        hipExtLaunchKernelGGL(kern, dim3(cdiv(Sq, qpw), heads, B), dim3(nthr), 0, s, e0, e1, 0, a);
     } else
-        hipLaunchKernelGGL(kern, dim3(cdiv(Sq, 128), heads, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(kern, dim3(cdiv(Sq, qpw), heads, B), dim3(nthr), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ctx_set_error("attention launch failed: %s", hipGetErrorString(e));
