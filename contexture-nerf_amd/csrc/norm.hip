@@ -557,43 +557,48 @@ int ctx_time_embed_f16(const float *t, int B, int dim, f16 *out, hipStream_t s)
 // One pixel per lane: its 9 x Cin inputs live in registers; the weights of this block's slice of output channels
 // sit in LDS and are read as wave-wide broadcasts; grid.y splits the output channels.
 #define CI_SPLIT 4
+// CP = padded input channels of the weight pack [Cout][3][3][CP]: 8 (latents + depth, VAE) or 16 (the 9-channel inpainting UNet)
+template <int CP>
 __global__ __launch_bounds__(256) void k_conv_in(const float *__restrict__ x, const f16 *__restrict__ w,
                                                  const f16 *__restrict__ bias, int B, int Cin, int H, int W, int Cout,
                                                  f16 *__restrict__ y)
 {
-    extern __shared__ __attribute__((aligned(16))) f16 s_w[];     // [o_per][72]
+    extern __shared__ __attribute__((aligned(16))) f16 s_w[];     // [o_per][9 * CP]
+    constexpr int WR = 9 * CP;
     const int o8n = Cout / 8;
     const int o8_per = (o8n + CI_SPLIT - 1) / CI_SPLIT;
     const int o8_0 = blockIdx.y * o8_per, o8_1 = min(o8n, o8_0 + o8_per);
-    const int nw = (o8_1 - o8_0) * 8 * 72;
-    for (int i = threadIdx.x; i < nw; i += 256) s_w[i] = w[(size_t)o8_0 * 8 * 72 + i];
+    const int nw = (o8_1 - o8_0) * 8 * WR;
+    for (int i = threadIdx.x; i < nw; i += 256) s_w[i] = w[(size_t)o8_0 * 8 * WR + i];
     __syncthreads();
     const int64_t npix = (int64_t)B * H * W;
     int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (pix >= npix) return;
     int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
     int oy = p / W, ox = p % W;
-    float in[9][8];
+    float in[9][CP];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
         bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < CP; ++c)
             in[t][c] = (ok && c < Cin) ? (float)(f16)x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
     }
     for (int o8 = o8_0; o8 < o8_1; ++o8) {
         f16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const f16 *wr = s_w + ((o8 - o8_0) * 8 + j) * 72;
+            const f16 *wr = s_w + ((o8 - o8_0) * 8 + j) * WR;
             float acc = (float)bias[o8 * 8 + j];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                f16x8 wv = *(const f16x8 *)(wr + t * 8);
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc += in[t][c] * (float)wv[c];
-            }
+                for (int c8 = 0; c8 < CP; c8 += 8) {
+                    f16x8 wv = *(const f16x8 *)(wr + t * CP + c8);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc += in[t][c8 + c] * (float)wv[c];
+                }
             o[j] = (f16)acc;
         }
         *(f16x8 *)(y + pix * Cout + o8 * 8) = o;
@@ -603,8 +608,10 @@ int ctx_conv_in_f16(const float *x, const f16 *w, const f16 *bias, int B, int Ci
 {
     int64_t npix = (int64_t)B * H * W;
     int o8_per = (Cout / 8 + CI_SPLIT - 1) / CI_SPLIT;
-    hipLaunchKernelGGL(k_conv_in, dim3((unsigned)cdiv64(npix, 256), CI_SPLIT), dim3(256), (size_t)o8_per * 8 * 72 * 2, s, x, w, bias, B, Cin,
-                       H, W, Cout, y);
+    if (Cin <= 8)
+        hipLaunchKernelGGL(k_conv_in<8>, dim3((unsigned)cdiv64(npix, 256), CI_SPLIT), dim3(256), (size_t)o8_per * 8 * 72 * 2, s, x, w, bias, B, Cin, H, W, Cout, y);
+    else
+        hipLaunchKernelGGL(k_conv_in<16>, dim3((unsigned)cdiv64(npix, 256), CI_SPLIT), dim3(256), (size_t)o8_per * 8 * 144 * 2, s, x, w, bias, B, Cin, H, W, Cout, y);
     return CTX_OK;
 }
 

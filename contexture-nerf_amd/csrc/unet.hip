@@ -170,7 +170,7 @@ static void add_transformer(ctx_unet *u, const std::string &p, int C, int heads,
 
 static ctx_unet_t *unet_create_impl(const ctx_unet_config_t *cfg, bool controlnet, int cond_channels)
 {
-    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->in_channels > 8 || cfg->out_channels > 4 ||
+    if (!cfg || cfg->n_levels < 1 || cfg->n_levels > 4 || cfg->in_channels > 16 || cfg->out_channels > 4 ||
         cfg->groups > 64 || cfg->layers_per_block < 1 || cfg->layers_per_block > 4 || cfg->cross_attention_dim % 64) {
         ctx_set_error("unet_create: unsupported config");
         return nullptr;
@@ -205,7 +205,8 @@ static ctx_unet_t *unet_create_impl(const ctx_unet_config_t *cfg, bool controlne
         u->kvw = u->walloc((size_t)kvr * cfg->cross_attention_dim);
     }
 
-    u->ciw = u->add("conv_in.weight", {ch[0], cfg->in_channels, 3, 3}, PK_CONVIN, u->walloc((size_t)ch[0] * 72), ch[0], cfg->in_channels);
+    u->ciw = u->add("conv_in.weight", {ch[0], cfg->in_channels, 3, 3}, PK_CONVIN, u->walloc((size_t)ch[0] * 9 * (cfg->in_channels > 8 ? 16 : 8)), ch[0],
+                    cfg->in_channels);
     u->cib = u->vec("conv_in.bias", ch[0]);
     u->t1w = u->lin("time_embedding.linear_1.weight", u->temb_dim, ch[0]); u->t1b = u->vec("time_embedding.linear_1.bias", u->temb_dim);
     u->t2w = u->lin("time_embedding.linear_2.weight", u->temb_dim, u->temb_dim); u->t2b = u->vec("time_embedding.linear_2.bias", u->temb_dim);
@@ -378,7 +379,7 @@ extern "C" int32_t ctx_unet_set_param(ctx_unet_t *u, int32_t i, const float *src
     switch (p.kind) {
     case PK_COPY: hipLaunchKernelGGL(k_pack_copy, dim3(nb), dim3(256), 0, s, src, n, d); break;
     case PK_CONV3: hipLaunchKernelGGL(k_pack_conv3, dim3(nb), dim3(256), 0, s, src, p.a, p.b, p.b, d); break;
-    case PK_CONVIN: hipLaunchKernelGGL(k_pack_conv3, dim3(nb), dim3(256), 0, s, src, p.a, p.b, 8, d); break;
+    case PK_CONVIN: hipLaunchKernelGGL(k_pack_conv3, dim3(nb), dim3(256), 0, s, src, p.a, p.b, p.b > 8 ? 16 : 8, d); break;
     case PK_GEGLU_W: hipLaunchKernelGGL(k_pack_geglu, dim3(nb), dim3(256), 0, s, src, p.a, p.b, d); break;
     case PK_GEGLU_B: hipLaunchKernelGGL(k_pack_geglu, dim3(nb), dim3(256), 0, s, src, p.a, 0, d); break;
     }

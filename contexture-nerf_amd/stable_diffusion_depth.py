@@ -40,6 +40,7 @@ class StableDiffusion:
         # `model_name` may be a LOCAL directory in the diffusers layout (unet/diffusion_pytorch_model.safetensors,
         # vae/diffusion_pytorch_model.safetensors): the files are read by safetensors_io (nothing is fetched by name offline)
         local = model_name if isinstance(model_name, str) and os.path.isdir(model_name) else None
+        self._local_dir, self._seed, self._inpaint_unet = local, seed, None
         unet_file = os.path.join(local, 'unet', 'diffusion_pytorch_model.safetensors') if local else None
         vae_file = os.path.join(local, 'vae', 'diffusion_pytorch_model.safetensors') if local else None
         from_file = unet is None and unet_state_dict is None and unet_file is not None and os.path.exists(unet_file)
@@ -59,6 +60,21 @@ class StableDiffusion:
         self.scheduler = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                                        num_train_timesteps=self.num_train_timesteps, steps_offset=1, skip_prk_steps=True)
         self.alphas = self.scheduler.alphas_cumprod.to(self.device)
+
+    @property
+    def inpaint_unet(self):
+        """The SD2-inpainting UNet the reference loads next to the depth UNet (`stabilityai/stable-diffusion-2-inpainting`,
+        in_channels 9, fp16; stable_diffusion_depth.py:73-88) and hands to the Zero123++ pipeline (trainer.py:312).  It never runs on
+        the reference's live path (use_inpaint stays False), so it is built on first access: same architecture, seeded random
+        init offline, or `<model_name>/inpaint_unet/diffusion_pytorch_model.safetensors` when model_name is a local directory."""
+        if getattr(self, '_inpaint_unet', None) is None:
+            cfg = dict(self.unet.config, in_channels=9)
+            f = os.path.join(self._local_dir, 'inpaint_unet', 'diffusion_pytorch_model.safetensors') if self._local_dir else None
+            if f and os.path.exists(f):
+                self._inpaint_unet = UNet2DConditionModel.from_file(f, cfg, device=self.device)
+            else:
+                self._inpaint_unet = UNet2DConditionModel(cfg, device=self.device, seed=self._seed + 1)
+        return self._inpaint_unet
 
     def get_text_embeds(self, prompt, negative_prompt=None, seed=0):
         """-> cat([uncond, cond]) [2,77,1024].  With no encoder (offline) a seeded random embedding stands in."""

@@ -266,6 +266,7 @@ class ConTEXTure:
         stack = DepthControlUNet(RefOnlyNoisedUNet(unet, DDPMScheduler(prediction_type="v_prediction"), psched).eval(), controlnet,
                                  conditioning_scale=2.0).eval()
         self.zero123plus = Zero123PlusPipeline(vae, stack, psched)
+        self.zero123plus.inpaint_unet_source = self.diffusion          # trainer.py:312, resolved on first use
         g = torch.Generator().manual_seed(seed + 14)
         self.zero123plus_prompt_embeds = torch.randn(1, 77, ucfg['cross_attention_dim'], generator=g).to(self.device)
         return self.zero123plus

@@ -89,6 +89,18 @@ class Zero123PlusPipeline:
     """Tensor-level mirror of the pipeline's __call__ (src/zero123plus.py:748-833) and of the denoising loop of run_sd_pipeline
     (:604-746, without the inpaint / blend branch).  unet = DepthControlUNet(RefOnlyNoisedUNet(...)) or RefOnlyNoisedUNet(...)."""
 
+    @property
+    def inpaint_unet(self):
+        """`pipeline.inpaint_unet = self.diffusion.inpaint_unet` (trainer.py:312): an engine set by the caller, or resolved on first
+        use from `inpaint_unet_source` (a StableDiffusion, which builds its 9-channel UNet lazily: it never runs on the live path)."""
+        v = self.__dict__.get('_inpaint_unet')
+        src = self.__dict__.get('inpaint_unet_source')
+        return v if v is not None or src is None else src.inpaint_unet
+
+    @inpaint_unet.setter
+    def inpaint_unet(self, v):
+        self.__dict__['_inpaint_unet'] = v
+
     def __init__(self, vae, unet, scheduler, ramping_coefficients=None):
         self.vae, self.unet, self.scheduler = vae, unet, scheduler
         self.ramping_coefficients = ramping_coefficients
@@ -99,10 +111,17 @@ class Zero123PlusPipeline:
     @torch.no_grad()
     def __call__(self, image, prompt_embeds=None, global_embeds=None, guidance_scale=4.0, depth_image=None, output_type="pt",
                  width=640, height=960, num_inference_steps=28, timesteps=None, latents=None, generator=None,
-                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",)):
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",),
+                 use_inpaint=False, use_blending=False, latent_mask_grid=None, latent_renders_grid=None, masked_input_latents=None):
         """image: [1,3,H,W] in [-1,1] (already resized / normalised for the VAE); depth_image: [1,3,height,width] in [0,1];
         prompt_embeds [1,77,D] (and optionally global_embeds [1,1,D], added with the ramping coefficients as :802-803).
-        -> images [1,3,height,width] in [0,1] (output_type 'pt') or the unscaled latents ('latent')."""
+        -> images [1,3,height,width] in [0,1] (output_type 'pt') or the unscaled latents ('latent').
+        ConTEXTure's inpaint / blend extension of run_sd_pipeline (src/zero123plus.py:436-440, 650-708), as the spec text has it:
+        use_blending — before every step outside the inpaint range the latents are re-anchored outside the mask,
+        `latents * mask + add_noise(<first argument>, randn, t) * (1 - mask)` (the spec passes `latent_mask_grid` itself as the
+        sample to noise, :654-659 — mirrored literally), and after the LAST step blended with the clean `latent_renders_grid`;
+        use_inpaint — steps 10 < i < 20 are predicted by `self.inpaint_unet` (SD2-inpainting layout: in_channels 9) on
+        cat([latents, latent_mask_grid, masked_input_latents]) instead of the reference-only / ControlNet stack."""
         dev = image.device
         inner = self.unet.unet if hasattr(self.unet, 'controlnet') else self.unet
         cfg = inner.unet.config
@@ -138,14 +157,34 @@ class Zero123PlusPipeline:
         if latents is None:
             latents = torch.randn(1, cfg['in_channels'], height // 8, width // 8, generator=generator, device=dev)
         latents = latents * sch.init_noise_sigma
+        if (use_inpaint or use_blending) and latent_mask_grid is None:
+            raise L.CtxError("Zero123PlusPipeline: use_inpaint / use_blending need latent_mask_grid")
+        if use_blending and latent_renders_grid is None:
+            raise L.CtxError("Zero123PlusPipeline: use_blending needs latent_renders_grid")
+        if use_inpaint and (masked_input_latents is None or getattr(self, 'inpaint_unet', None) is None):
+            raise L.CtxError("Zero123PlusPipeline: use_inpaint needs masked_input_latents and pipeline.inpaint_unet (trainer.py:312)")
+        n_steps = len(sch.timesteps)
         for i, t in enumerate(sch.timesteps):
-            x = torch.cat([latents] * 2) if do_cfg else latents
-            x = sch.scale_model_input(x, t)
-            noise_pred = self.unet(x, t.reshape(1), prompt_embeds, cross_attention_kwargs=cak)['sample']
+            is_inpaint_range = use_inpaint and (10 < i < 20)                                    # :650
+            if not is_inpaint_range and use_blending:                                           # :651-661
+                noises_latent = torch.randn(latents.shape, generator=generator, device=dev, dtype=latents.dtype)
+                noised = sch.add_noise(latent_mask_grid, noises_latent, t.reshape(1).cpu())
+                latents = latents * latent_mask_grid + noised * (1 - latent_mask_grid)
+            if not is_inpaint_range:
+                x = torch.cat([latents] * 2) if do_cfg else latents
+                x = sch.scale_model_input(x, t)
+                noise_pred = self.unet(x, t.reshape(1), prompt_embeds, cross_attention_kwargs=cak)['sample']
+            else:                                                                               # :676-690
+                xin = torch.cat([latents, latent_mask_grid, masked_input_latents], dim=1)
+                xin = torch.cat([xin] * 2) if do_cfg else xin
+                xin = sch.scale_model_input(xin, t)
+                noise_pred = self.inpaint_unet(xin, float(t), encoder_hidden_states=prompt_embeds)['sample']
             if do_cfg:
                 nu, nt = noise_pred.chunk(2)
                 noise_pred = nu + guidance_scale * (nt - nu)
             latents = sch.step(noise_pred, t, latents, generator=generator)['prev_sample']
+            if i == n_steps - 1 and use_blending:                                               # :705-708
+                latents = latents * latent_mask_grid + latent_renders_grid * (1 - latent_mask_grid)
             if callback_on_step_end is not None:
                 loc = dict(latents=latents, noise_pred=noise_pred, prompt_embeds=prompt_embeds)
                 out = callback_on_step_end(self, i, t, {k: loc[k] for k in callback_on_step_end_tensor_inputs})

@@ -384,3 +384,52 @@ def test_paint_zero123plus_loop_and_eval(dev, tmp_path):
     assert tr.fitted_pred_rgb.shape == rgb.shape and float(tr.atlas_contrib[3].sum()) > 0
     m = (obj > 0).expand_as(rgb)
     assert float((tr.fitted_pred_rgb - rgb)[m].abs().mean()) < 0.08       # the scattered atlas reproduces the view it was painted from
+
+
+def test_zero123plus_inpaint_and_blend_extension(dev):
+    """ConTEXTure's extension of the Zero123++ denoising loop (spec: src/zero123plus.py:436-440, 650-708) on tiny engines:
+    with use_blending the result outside the mask is the clean render latents (final blend) and every non-inpaint step
+    re-anchors the latents; with use_inpaint steps 11..19 are predicted by the 9-channel inpaint UNet on
+    cat([latents, mask, masked_input_latents]); the plain call is unchanged."""
+    from contexture_nerf_amd.unet import UNet2DConditionModel
+    from contexture_nerf_amd.vae import AutoencoderKL
+    from contexture_nerf_amd.scheduler import EulerAncestralDiscreteScheduler, DDPMScheduler
+    from contexture_nerf_amd.zero123plus import RefOnlyNoisedUNet, Zero123PlusPipeline, unscale_latents
+    from contexture_nerf_amd._lib import CtxError
+    from oracle import unet_ref
+    cfg = unet_ref.tiny_config(in_channels=4)
+    net = UNet2DConditionModel(cfg, device=dev, seed=1)
+    vae = AutoencoderKL(dict(latent_channels=4, out_channels=3, block_out_channels=(64, 128, 128, 128), layers_per_block=1, groups=32), device=dev, seed=3)
+    sch = EulerAncestralDiscreteScheduler()
+    pipe = Zero123PlusPipeline(vae, RefOnlyNoisedUNet(net, DDPMScheduler(), sch).eval(), sch)
+    g = torch.Generator().manual_seed(4)
+    image = (torch.rand(1, 3, 64, 64, generator=g) * 2 - 1).to(dev)
+    pe = torch.randn(1, 9, cfg['cross_attention_dim'], generator=g).to(dev)
+    mask = (torch.rand(1, 1, 24, 16, generator=g) > 0.5).float().to(dev)                       # one channel: 4 + 1 + 4 = the inpaint UNet's 9
+    renders = torch.randn(1, 4, 24, 16, generator=g).to(dev)
+    masked_in = torch.randn(1, 4, 24, 16, generator=g).to(dev)
+    kw = dict(prompt_embeds=pe, guidance_scale=4.0, num_inference_steps=22, width=128, height=192, output_type='latent')
+    with pytest.raises(CtxError, match="latent_mask_grid"):
+        pipe(image, use_blending=True, **kw)
+    out = pipe(image, use_blending=True, latent_mask_grid=mask, latent_renders_grid=renders, generator=torch.Generator(device=dev).manual_seed(1), **kw).images
+    assert torch.isfinite(out).all()
+    outside = (mask == 0).expand(1, 4, 24, 16)
+    assert torch.allclose(out[outside], unscale_latents(renders)[outside], atol=1e-6)           # final blend keeps the clean renders
+    assert not torch.allclose(out[~outside], unscale_latents(renders)[~outside], atol=1e-3)
+    with pytest.raises(CtxError, match="inpaint_unet"):
+        pipe(image, use_inpaint=True, latent_mask_grid=mask, masked_input_latents=masked_in, **kw)
+    inp = UNet2DConditionModel(dict(cfg, in_channels=9), device=dev, seed=5)
+    calls = []
+
+    class Spy:
+        def __call__(self, x, t, encoder_hidden_states=None):
+            calls.append((tuple(x.shape), float(t)))
+            assert torch.equal(x[:, 4:5] > 0, torch.cat([mask] * 2) > 0)       # the mask rides in channel 4 (scaled with the rest, as the spec does)
+            return inp(x, t, encoder_hidden_states=encoder_hidden_states)
+    pipe.inpaint_unet = Spy()
+    out2 = pipe(image, use_inpaint=True, use_blending=True, latent_mask_grid=mask, latent_renders_grid=renders, masked_input_latents=masked_in,
+                generator=torch.Generator(device=dev).manual_seed(1), **kw).images
+    assert len(calls) == 9 and all(s == (2, 9, 24, 16) for s, _ in calls)                        # steps 11..19, CFG pair, 4 + 1x4 + 4 channels
+    assert torch.isfinite(out2).all() and torch.allclose(out2[outside], unscale_latents(renders)[outside], atol=1e-6)
+    plain = pipe(image, generator=torch.Generator(device=dev).manual_seed(1), **kw).images
+    assert not torch.equal(plain, out)
