@@ -409,6 +409,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a)
 //   5: 64x64 4w (32x32 per wave)   6: 64x64 2w (64x32)   7: 128x128 8w (32x64)   8: 64x128 4w (32x64)   9: 128x64 4w (64x32)
 //   10-18: 64-deep K stages, ring of 3: 256x128 16w (32x64) | 256x128 16w (64x32) | 256x128 8w | 128x128 16w (32x32) | 128x128 8w |
 //          64x64 4w | 64x128 4w | 128x64 4w | 128x128 4w;  19-22: ring of 2: 64x64 4w | 128x128 8w | 128x128 16w | 128x128 4w
+//   23-26: deep rings: 64x64 4w x6 | 64x128 4w x5 | 128x128 8w x4 | 128x64 4w x5
 static int g_force_tile = -1, g_force_gemm8 = -1;
 extern "C" void ctx_gemm_tune(int32_t tile, int32_t gemm8)
 {
@@ -547,7 +548,7 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
         if (force == -2) { const char *e = getenv("CTX_GEMM_TILE"); force = e ? atoi(e) : -1; }
         if (force >= 0) pick = force;
         if (want_tile >= 0) pick = want_tile;
-        if (a.epi == 1 && (pick == 5 || pick == 6 || pick == 9 || pick == 11 || pick == 13 || pick == 15 || pick == 17 || pick == 19 || pick == 21)) pick = 1;   // GEGLU needs 64-wide wave tiles
+        if (a.epi == 1 && (pick == 5 || pick == 6 || pick == 9 || pick == 11 || pick == 13 || pick == 15 || pick == 17 || pick == 19 || pick == 21 || pick == 23 || pick == 26)) pick = 1;   // GEGLU needs 64-wide wave tiles
         if (pick >= 10 && (a.K % 64 != 0 || (conv && a.Cin % 64 != 0))) pick = 1;   // 64-deep stages
 #define CTX_LAUNCH(WM_, WN_, MI_, NI_) do { if (conv) launch_gemm<WM_, WN_, MI_, NI_, true>(a, s); else launch_gemm<WM_, WN_, MI_, NI_, false>(a, s); } while (0)
         switch (pick) {
@@ -575,7 +576,15 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
         case 19: CTX_LAUNCH64N2(2, 2, 1, 1); break;   // ring of 2 (half the LDS, more workgroups per CU): 64x64, 4 waves
         case 20: CTX_LAUNCH64N2(4, 2, 1, 2); break;   // 128x128, 8 waves
         case 21: CTX_LAUNCH64N2(4, 4, 1, 1); break;   // 128x128, 16 waves
-        default: CTX_LAUNCH64N2(2, 2, 2, 2); break;   // 22: 128x128, 4 waves
+        case 22: CTX_LAUNCH64N2(2, 2, 2, 2); break;   // 128x128, 4 waves
+        // deep rings (one workgroup per CU, 4-5 stages in flight) for the weight-streaming layers of the two deepest levels,
+        // whose few workgroups wait on HBM latency rather than on staging bandwidth
+#define CTX_LAUNCH64NS(NS_, WM_, WN_, MI_, NI_) do { if (conv) launch_gemm<WM_, WN_, MI_, NI_, true, NS_, 64>(a, s); else launch_gemm<WM_, WN_, MI_, NI_, false, NS_, 64>(a, s); } while (0)
+        case 23: CTX_LAUNCH64NS(6, 2, 2, 1, 1); break;   // 64x64, 4 waves, ring of 6
+        case 24: CTX_LAUNCH64NS(5, 2, 2, 1, 2); break;   // 64x128, 4 waves, ring of 5
+        case 25: CTX_LAUNCH64NS(4, 4, 2, 1, 2); break;   // 128x128, 8 waves, ring of 4
+        default: CTX_LAUNCH64NS(5, 2, 2, 2, 1); break;   // 26: 128x64, 4 waves, ring of 5
+#undef CTX_LAUNCH64NS
 #undef CTX_LAUNCH64N2
 #undef CTX_LAUNCH64
         }

@@ -2,15 +2,17 @@
 """Copy what tools/refresh_profiles.sh produced (gpurun_out/prof_refresh/) into profiles/ (names truncated, noise stripped)."""
 import csv, glob, shutil, collections, os
 O = 'gpurun_out/prof_refresh'
-shutil.copy(f'{O}/r01_bench_default.json', 'profiles/r01_bench_default.json')
-shutil.copy(f'{O}/traffic.json', 'profiles/r01_pmc_traffic.json')
-shutil.copy(f'{O}/r01_bench_by_kernel_and_grid.txt', 'profiles/r01_bench_by_kernel_and_grid.txt')
-for f in ('r01_mesh_bench.json', 'r01_views_in_flight.txt', 'r01_uvmlp_bench.json', 'r01_volume_bench.json', 'r01_zero123_bench.json', 'r01_sds_iter_bench.json'):
+R = os.environ.get('ROUND', 'r02')
+shutil.copy(f'{O}/{R}_bench_default.json', f'profiles/{R}_bench_default.json')
+shutil.copy(f'{O}/traffic.json', f'profiles/{R}_pmc_traffic.json')
+shutil.copy(f'{O}/{R}_bench_by_kernel_and_grid.txt', f'profiles/{R}_bench_by_kernel_and_grid.txt')
+for f in (f'{R}_mesh_bench.json', f'{R}_views_in_flight.txt', f'{R}_uvmlp_bench.json', f'{R}_volume_bench.json', f'{R}_zero123_bench.json', f'{R}_sds_loop_bench.json',
+          f'{R}_mesh_batch_bench.json', f'{R}_bench_mesh_mode.json', f'{R}_gemm_square.txt'):
     if os.path.exists(f'{O}/{f}'):
         shutil.copy(f'{O}/{f}', f'profiles/{f}')
-for src, dst in ((f'{O}/r01_geometry_bench.jsonl', 'profiles/r01_geometry_bench.jsonl'), (f'{O}/r01_gemm_layers.txt', 'profiles/r01_gemm_layers.txt')):
+for src, dst in ((f'{O}/{R}_geometry_bench.jsonl', f'profiles/{R}_geometry_bench.jsonl'), (f'{O}/{R}_gemm_layers.txt', f'profiles/{R}_gemm_layers.txt')):
     open(dst, 'w').writelines(l for l in open(src) if 'amdgpu.ids' not in l)
-for tag, out in (('unet', 'profiles/r01_bench_kernel_stats.csv'), ('geom', 'profiles/r01_geometry_kernel_stats.csv')):
+for tag, out in (('unet', f'profiles/{R}_bench_kernel_stats.csv'), ('geom', f'profiles/{R}_geometry_kernel_stats.csv')):
     f = glob.glob(f'{O}/{tag}/*/*kernel_stats.csv')[0]
     rows = list(csv.reader(open(f)))
     with open(out, 'w', newline='') as o:
@@ -23,7 +25,9 @@ for r in csv.DictReader(open(t)):
     n = r['Kernel_Name']
     if 'k_' in n and 'at::' not in n:
         agg[n[:60]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-with open('profiles/r01_geometry_by_kernel.txt', 'w') as f:
+with open(f'profiles/{R}_geometry_by_kernel.txt', 'w') as f:
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         v = sorted(v); f.write(f"{k:62s} n={len(v):4d} median {v[len(v) // 2]:9.1f} us  min {v[0]:9.1f} us\n")
-print(open('profiles/r01_bench_default.json').read()[:200])
+if os.path.exists(f'{O}/mfma.txt'):
+    shutil.copy(f'{O}/mfma.txt', f'profiles/{R}_pmc_mfma.txt')
+print(open(f'profiles/{R}_bench_default.json').read()[:200])

@@ -83,8 +83,8 @@ for s_ in shapes:
         splits += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // 32 // s >= 4 and s * M * N * 4 <= part.numel()]
     cands = []
     for S in splits:
-        for tile in range(23):
-            if epi == 1 and tile in (5, 6, 9, 11, 13, 15, 17, 19, 21): continue
+        for tile in range(27):
+            if epi == 1 and tile in (5, 6, 9, 11, 13, 15, 17, 19, 21, 23, 26): continue
             if tile >= 10 and (K % 64 or (s_[0] == 1 and Cin % 64)): continue
             t = run(tile, 0, S)
             if t: cands.append((t, tile, 0, S))
