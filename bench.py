@@ -290,6 +290,8 @@ def main():
             del tr
         except Exception as e:                              # never lose the steps/s line to the mesh leg
             mesh_s, mesh_cover = None, f"failed: {e}"
+            import traceback
+            traceback.print_exc()
 
     # HBM-side bytes per launch of the dominant kernel family: PMC counters cannot be collected from inside this process,
     # so the figure is the committed result of tools/pmc_traffic.sh (same command line, same workload) when present

@@ -13,6 +13,7 @@ def init(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
+        local = local % max(torch.cuda.device_count(), 1)      # rehearsal: several ranks may share one card
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
