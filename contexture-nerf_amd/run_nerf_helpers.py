@@ -183,7 +183,18 @@ class NeRF2D(nn.Module):
         return raw
 
     def texture_map(self, res):
-        """textured_mesh.py:266-301 fused: -> (texture [1,C,res,res] in [0,1], mlp_output [res*res, C])."""
+        """textured_mesh.py:266-301 fused: -> (texture [1,C,res,res] in [0,1], mlp_output [res*res, C]).
+        The reference re-evaluates the field on every render() (2x per painted view, 3x per eval view); without gradients the
+        atlas only changes when a parameter does, so the no-grad result is kept until the parameters' version moves."""
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            key = (self._version(), res)
+            hit = getattr(self, '_tex_cache', None)
+            if hit is not None and hit[0] == key:
+                return hit[1], hit[2]
+            raw, tex = self._run(None, None, res * res, res, True)
+            out = (tex.reshape(1, self.output_ch, res, res), raw)
+            self._tex_cache = (key, out[0], out[1])
+            return out
         raw, tex = self._run(None, None, res * res, res, True)
         return tex.reshape(1, self.output_ch, res, res), raw
 
