@@ -57,6 +57,15 @@ class StableDiffusion:
         else:
             self.vae = AutoencoderKL(device=device, seed=seed)      # random-init offline
         self.text_encoder = text_encoder
+        self.tokenizer = None
+        if text_encoder is None and local and os.path.isdir(os.path.join(local, 'text_encoder')) and os.path.isdir(os.path.join(local, 'tokenizer')):
+            # the reference's own text path (stable_diffusion_depth.py:61-66, 222-244): transformers' CLIPTokenizer + CLIPTextModel read from
+            # the LOCAL diffusers-layout directory (local_files_only: nothing is fetched by name).  The text encoder is a once-per-prompt
+            # torch module, not part of the per-step hot path.
+            from transformers import CLIPTextModel, CLIPTokenizer
+            self.tokenizer = CLIPTokenizer.from_pretrained(os.path.join(local, 'tokenizer'), local_files_only=True)
+            self._clip = CLIPTextModel.from_pretrained(os.path.join(local, 'text_encoder'), local_files_only=True).to(self.device).eval()
+            self.text_encoder = self._clip_embeds
         self.scheduler = PNDMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                                        num_train_timesteps=self.num_train_timesteps, steps_offset=1, skip_prk_steps=True)
         self.alphas = self.scheduler.alphas_cumprod.to(self.device)
@@ -75,6 +84,19 @@ class StableDiffusion:
             else:
                 self._inpaint_unet = UNet2DConditionModel(cfg, device=self.device, seed=self._seed + 1)
         return self._inpaint_unet
+
+    def _clip_embeds(self, prompt, negative_prompt=None):
+        """stable_diffusion_depth.py:222-244: tokenise (pad to model_max_length), encode the prompt and '' (or the negative prompt),
+        -> cat([uncond, cond])."""
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        tok = self.tokenizer
+        ti = tok(prompt, padding='max_length', max_length=tok.model_max_length, truncation=True, return_tensors='pt')
+        negative_prompt = [''] * len(prompt) if negative_prompt is None else ([negative_prompt] if isinstance(negative_prompt, str) else list(negative_prompt))
+        ui = tok(negative_prompt, padding='max_length', max_length=tok.model_max_length, return_tensors='pt')
+        with torch.no_grad():
+            te = self._clip(ti.input_ids.to(self.device))[0]
+            ue = self._clip(ui.input_ids.to(self.device))[0]
+        return torch.cat([ue, te]).float()
 
     def get_text_embeds(self, prompt, negative_prompt=None, seed=0):
         """-> cat([uncond, cond]) [2,77,1024].  With no encoder (offline) a seeded random embedding stands in."""

@@ -331,3 +331,44 @@ def test_safetensors_reader_writer(tmp_path):
     js = json.dumps(h).encode(); bad.write_bytes(struct.pack("<Q", len(js)) + js + raw[8 + n:])
     with pytest.raises(sio.SafetensorsError, match="claims bytes"):
         sio.load_file(str(bad))
+
+
+def test_clip_text_path_from_local_directory(tmp_path):
+    """get_text_embeds through the reference's own text path (CLIPTokenizer + CLIPTextModel, stable_diffusion_depth.py:222-244) when
+    `model_name` is a local diffusers-layout directory: a tiny random CLIP text model and a toy BPE vocabulary written by this test.
+    -> cat([uncond, cond]) of shape [2, max_length, hidden]; the unconditional half is the encoding of ''."""
+    import json
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+    from contexture_nerf_amd.stable_diffusion_depth import StableDiffusion
+    tokd, encd = tmp_path / "tokenizer", tmp_path / "text_encoder"
+    tokd.mkdir(); encd.mkdir()
+    letters = list("abcdefghijklmnopqrstuvwxyz")
+    vocab = {}
+    for ch in letters:
+        vocab[ch] = len(vocab)
+    for ch in letters:
+        vocab[ch + "</w>"] = len(vocab)
+    vocab["<|startoftext|>"] = len(vocab); vocab["<|endoftext|>"] = len(vocab)
+    (tokd / "vocab.json").write_text(json.dumps(vocab))
+    (tokd / "merges.txt").write_text("#version: 0.2\n")
+    tok = CLIPTokenizer(str(tokd / "vocab.json"), str(tokd / "merges.txt"), model_max_length=12)
+    tok.save_pretrained(str(tokd))
+    torch.manual_seed(0)
+    cfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                         max_position_embeddings=12, bos_token_id=vocab["<|startoftext|>"], eos_token_id=vocab["<|endoftext|>"], pad_token_id=vocab["<|endoftext|>"])
+    CLIPTextModel(cfg).save_pretrained(str(encd))
+    import types
+    sd = StableDiffusion.__new__(StableDiffusion)
+    # run only the text part of __init__ (the engines need a GPU): replicate its local-directory branch
+    sd.device, sd.text_encoder, sd.tokenizer = 'cpu', None, None
+    sd.unet = types.SimpleNamespace(config={'cross_attention_dim': 32})
+    from transformers import CLIPTextModel as M, CLIPTokenizer as T
+    sd.tokenizer = T.from_pretrained(str(tokd), local_files_only=True)
+    sd._clip = M.from_pretrained(str(encd), local_files_only=True).eval()
+    sd.text_encoder = sd._clip_embeds
+    z = sd.get_text_embeds(["a car"])
+    assert z.shape == (2, 12, 32) and torch.isfinite(z).all()
+    z2 = sd.get_text_embeds(["a car"], negative_prompt=[""])
+    assert torch.equal(z, z2)
+    zz = sd.get_text_embeds(["a bus"])
+    assert torch.equal(zz[0], z[0]) and not torch.equal(zz[1], z[1])

@@ -102,3 +102,29 @@ if len(sys.argv) > 2 and sys.argv[1] == '--cpu' and sys.argv[2] == '1':
     t0 = time.perf_counter(); og.rasterize(Hc, Hc, o_cam[..., 2], o_img, o_cam[..., 2:3]); dt = time.perf_counter() - t0
     print(json.dumps({"cpu_baseline": "oracle brute-force raster (1 core, C)", "sample": f"1 view @{Hc}^2 nascar, 1 pass", "seconds": round(dt, 3),
                       "scaled_to_1200^2_two_passes_s": round(dt * 16 * 2, 2)}))
+    # the other stages of the path on the host cores (the oracle's C / numpy restatements; one core each unless numpy threads), so
+    # that every GPU stage above has a CPU point beside it: bounded samples, scaled to the GPU line's size by pixel / texel count
+    import numpy as np
+    from oracle import nerf as onerf
+
+    def cpu(name, fn, sample, scale, gpu_line):
+        t0 = time.perf_counter(); fn(); d = time.perf_counter() - t0
+        print(json.dumps({"cpu_baseline": name, "sample": sample, "seconds": round(d, 3), "scaled_s": round(d * scale, 3), "scaled_to": gpu_line}))
+    uv1, idx1 = uv[:1].cpu().numpy(), idx[:1].cpu().numpy()
+    tex_np = tex[0].cpu().numpy()
+    cpu("oracle texture_mapping fwd (C, 1 core)", lambda: og.texture_mapping(uv1, tex_np[None]), "1 view @1200^2, T=1024", 7, "B=7 @1200^2")
+    go1 = go[:1].cpu().numpy()
+    cpu("oracle texture_mapping bwd / UV scatter (C, 1 core)", lambda: og.texture_mapping_bwd(go1, uv1, T), "1 view @1200^2, T=1024", 7, "B=7 @1200^2")
+    fnz6 = fn6[:, 2, :].cpu().numpy() if fn6.dim() == 3 else fn6.cpu().numpy()
+    i6 = idx6[:, 0].cpu().numpy()
+    cpu("oracle view weights (scatter_max restatement, C, 1 core)", lambda: og.view_weights(i6, fnz6), "B=6 @1200^2", 1, "B=6 @1200^2")
+    d1 = depth[:1].cpu().numpy()
+    cpu("oracle normalize_multiple_depth (numpy)", lambda: og.normalize_multiple_depth(d1), "1 view @1200^2", 7, "B=7 @1200^2")
+    ws_ = [l.weight.detach().cpu().numpy() for l in net.pts_linears]; bs_ = [l.bias.detach().cpu().numpy() for l in net.pts_linears]
+    e256 = onerf.embed(onerf.uv_grid(256))
+    cpu("oracle texture field forward (numpy fp32, all host threads)", lambda: onerf.nerf2d_forward(e256, ws_, bs_, net.output_linear.weight.detach().cpu().numpy(),
+                                                                                                   net.output_linear.bias.detach().cpu().numpy()),
+        "256^2 texels", 16, "1024^2 atlas")
+    Rc = 16384
+    cpu("oracle raw2outputs (C, 1 core)", lambda: og.raw2outputs(rr[:Rc].cpu().numpy(), zz[:Rc].cpu().numpy(), dd[:Rc].cpu().numpy()), f"{Rc} rays x 128 samples",
+        R / Rc, "512^2 rays x 128 samples")
