@@ -96,6 +96,7 @@ SIGNATURES = {
     "ctx_bench_gemm": (C.c_float, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "ctx_gemm_tune": (None, [_i32, _i32]),
     "ctx_probe_mfma": (_i32, [_i32, _vp, _vp, _vp, _vp]),
+    "ctx_probe_stage": (C.c_float, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctx_cfg_plms_step": (_i32, [_vp, _i64, _f32, _vp, _i32, _vp, _f32, _f32, _i32, _vp, _vp, _vp]),
 }
 

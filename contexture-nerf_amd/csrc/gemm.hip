@@ -525,7 +525,9 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
     if (only_pipe) a.use8 = 0;
     const int want8 = only_pipe ? 0 : (g_force_gemm8 >= 0 ? g_force_gemm8 : a.use8);          // -1: gemm8's own heuristic
     const int want_tile = g_force_tile >= 0 ? g_force_tile : (g_force_gemm8 >= 0 ? -1 : a.tile);
-    if (want_tile < 0 && conv && (want8 == 2 || want8 == 3) && ctx_conv_halo_try(a, want8 == 2 ? 2 : 1, s)) {
+    if (want_tile < 0 && want8 >= 4 && want8 <= 8 && ctx_gemm144_try(a, conv, want8 - 4, s)) {
+        if (a.splitk > 1) launch_reduce(a, s);
+    } else if (want_tile < 0 && conv && (want8 == 2 || want8 == 3) && ctx_conv_halo_try(a, want8 == 2 ? 2 : 1, s)) {
         if (a.splitk > 1) launch_reduce(a, s);
     } else if (want_tile < 0 && want8 != 0 && want8 < 2 && ctx_gemm8_try(a, conv, want8 == 1, s)) {
         if (a.splitk > 1) launch_reduce(a, s);
@@ -691,11 +693,15 @@ __global__ __launch_bounds__(256) void k_gemv_f16(const f16 *__restrict__ x, con
 int ctx_gemv_f16(const f16 *x, const f16 *w, const f16 *bias, int Bm, int N, int K, int silu_in, int silu_out, f16 *out,
                  hipStream_t s)
 {
-    if (Bm > 4 || K % 8 != 0 || K < 8) {
-        ctx_set_error("gemv: Bm=%d (<=4) K=%d (%%8)", Bm, K);
+    if (Bm < 1 || K % 8 != 0 || K < 8) {
+        ctx_set_error("gemv: Bm=%d (>=1) K=%d (%%8)", Bm, K);
         return CTX_E_ARG;
     }
-    hipLaunchKernelGGL(k_gemv_f16, dim3(cdiv(N, 8)), dim3(256), 0, s, x, w, bias, Bm, N, K, silu_in, silu_out, out);
+    for (int b0 = 0; b0 < Bm; b0 += 4) {                       // four rows per pass over the weights
+        const int nb = Bm - b0 < 4 ? Bm - b0 : 4;
+        hipLaunchKernelGGL(k_gemv_f16, dim3(cdiv(N, 8)), dim3(256), 0, s, x + (size_t)b0 * K, w, bias, nb, N, K, silu_in, silu_out,
+                           out + (size_t)b0 * N);
+    }
     return CTX_OK;
 }
 

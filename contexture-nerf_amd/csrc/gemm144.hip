@@ -1,0 +1,260 @@
+// 144x160x64 fp16 MFMA GEMM / implicit-GEMM 3x3 convolution (gfx950): the tile that divides the UNet evenly over 256 CUs.
+//
+//   out[M,N] = X[M,K] . Wt[N,K]^T  (+bias)(+rowbias)(+residual) | fp32 split-K partials
+//
+// Replaces the cuBLAS / cuDNN calls under diffusers' UNet2DConditionModel (reference call site
+// src/stable_diffusion_depth.py:422-423).  Why this shape: at the reference's 768^2 image (latent 96^2, CFG batch 2) the four
+// UNet levels have M = 18432 / 4608 / 1152 / 288 tokens and N = 320 k features.  18432 x 320 outputs are exactly 256 tiles of
+// 144 x 160 (one per CU, nothing masked), and the deeper levels are 128 / 64 / 16 such tiles: split-K by 2 / 4 / 16 gives 256
+// workgroups again.  The 128- and 256-wide tiles of gemm.hip / gemm8.hip leave 16-30 % of the CUs idle or of the tile masked
+// on these shapes (N = 320 is 2.5 tiles of 128), and their time is set by the bytes a CU stages per K step.
+//
+// Structure: WM x WN waves over the tile's 9 x 10 blocks of 16 x 16: 3 x 2 (wave tile 48 tokens x 80 features, 15 accumulators
+// of v_mfma_f32_16x16x32_f16) or 3 x 5 (48 x 32, 6 accumulators, 15 waves: 4 / 4 / 4 / 3 per SIMD); weights = A operand,
+// activations = B operand, so a lane owns one token and 4 consecutive features per accumulator.  Operand tiles go global -> LDS
+// by global_load_lds_dwordx4 in 1-KiB pieces (8 rows x 128 B; 18 activation + 20 weight pieces per 64-deep K stage, dealt
+// round-robin to the waves: a wave has SL or SL - 1 of them and waits with its own immediate vmcnt count), ring of 3 stages,
+// one raw s_barrier per stage.
+// LDS image and fragment reads as gemm8.hip (16-byte chunk index XORed with (row>>1)&7 on the DMA source and on the read).
+#include "common.h"
+#include "kernels.h"
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
+typedef const __attribute__((address_space(1))) void *g144_gptr_t;
+typedef __attribute__((address_space(3))) void *g144_lptr_t;
+__device__ __attribute__((aligned(128))) f16 g144_zero[64];
+
+#define G144_BM 144
+#define G144_BN 160
+#define G144_STAGE ((G144_BM + G144_BN) * 64)      // f16 per stage
+
+__device__ __forceinline__ int g144_xcd_remap(int bid, int nwg)
+{
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <int WM, int WN, bool CONV, int NS, int VAR>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
+{
+    constexpr int NW = WM * WN, MI = 9 / WM, NI = 10 / WN;          // waves; 16x16 blocks per wave along tokens / features
+    constexpr int NP = 38;                                          // DMA pieces per stage: 18 activation + 20 weight (8 rows x 128 B)
+    constexpr int SL = (NP + NW - 1) / NW;                          // piece slots per wave (the last one empty on some waves)
+    static_assert(9 % WM == 0 && 10 % WN == 0, "wave grid must divide 9 x 10 blocks");
+    extern __shared__ __attribute__((aligned(16))) f16 smem[];     // [NS][144 X rows | 160 W rows][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, kg = lane >> 4;
+
+    const int ntiles = a.ntm * a.ntn;
+    const int lin = g144_xcd_remap(blockIdx.x, ntiles * a.splitk);
+    const int slice = lin / ntiles, bid = lin - slice * ntiles;
+    const int tile_n = a.mfast ? bid / a.ntm : bid % a.ntn, tile_m = a.mfast ? bid % a.ntm : bid / a.ntn;
+    const int m0 = tile_m * G144_BM, n0 = tile_n * G144_BN;
+    const int nk_all = a.K / 64;
+    const int kbeg = (int)((long)nk_all * slice / a.splitk);
+    const int nk = (int)((long)nk_all * (slice + 1) / a.splitk) - kbeg;
+
+    // ---- DMA state: piece p = wave + NW i of the stage image; p < 18 activation rows 8p.., else weight rows 8(p-18).. -----
+    const int prow = lane >> 3, pc = lane & 7;
+    const f16 *pp[SL];
+    int pst[SL], xoff[SL], xoy[SL], xox[SL], xlc[SL];
+    bool xok[SL];
+    const bool full = wave + NW * (SL - 1) < NP;                    // this wave uses its last slot
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+        const int p = wave + NW * i;
+        const bool isx = p < 18, live = p < NP;
+        const int s = isx ? 8 * p + prow : 8 * (p - 18) + prow;     // row inside the activation / weight tile
+        xlc[i] = (pc ^ ((s >> 1) & 7)) * 8;
+        xoff[i] = 0; xoy[i] = 0; xox[i] = 0;
+        if (isx) {
+            const int m = m0 + s;
+            xok[i] = m < a.M;
+            if (CONV) {
+                const int hw = a.Ho * a.Wo;
+                const int mm = xok[i] ? m : 0;
+                const int b = mm / hw, q = mm - b * hw;
+                const int oy = q / a.Wo, ox = q - oy * a.Wo;
+                xoy[i] = oy * a.stride; xox[i] = ox * a.stride;
+                xoff[i] = b * a.H * a.W * a.Cin;
+                pp[i] = g144_zero; pst[i] = 0;
+            } else {
+                pp[i] = xok[i] ? a.X + (size_t)m * a.K + (size_t)kbeg * 64 + xlc[i] : g144_zero;
+                pst[i] = xok[i] ? 64 : 0;
+            }
+        } else {
+            const bool ok = live && (n0 + s) < a.N;
+            xok[i] = ok;
+            pp[i] = ok ? a.Wt + (size_t)(n0 + s) * a.K + (size_t)kbeg * 64 + xlc[i] : g144_zero;
+            pst[i] = ok ? 64 : 0;
+        }
+    }
+
+    int k_issue = kbeg * 64, issued = 0, tap_left = 0;
+    auto retap = [&]() {                                            // CONV: new 3x3 tap -> recompute the activation pointers
+        const int tap = k_issue / a.Cin, c0 = k_issue - tap * a.Cin;
+        const int dy = tap / 3 - 1 + a.poff, dx = tap % 3 - 1 + a.poff;
+        const int Hv = a.H << a.ups, Wv = a.W << a.ups;
+#pragma unroll
+        for (int i = 0; i < SL; ++i) {
+            if (wave + NW * i >= 18) continue;
+            const int iy = xoy[i] + dy, ix = xox[i] + dx;
+            const bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+            pp[i] = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 + xlc[i] : g144_zero;
+            pst[i] = ok ? 64 : 0;
+        }
+        tap_left = (a.Cin - c0) / 64;
+    };
+    auto issue = [&](int buf) {
+        if (CONV) {
+            if (tap_left == 0) retap();
+            --tap_left;
+        }
+        f16 *st = smem + buf * G144_STAGE;
+#pragma unroll
+        for (int i = 0; i < SL; ++i) {
+            const int p = wave + NW * i;
+            if (p < NP) {
+                __builtin_amdgcn_global_load_lds((g144_gptr_t)pp[i], (g144_lptr_t)(st + p * 512), 16, 0, 0);
+                pp[i] += pst[i];
+            }
+        }
+        k_issue += 64;
+        ++issued;
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int swz = (r16 >> 1) & 7;
+    const int ck[2] = {(kg ^ swz) * 8, ((4 + kg) ^ swz) * 8};
+    const int xrow = (wm * 16 * MI + r16) * 64, wrow = G144_BM * 64 + (wn * 16 * NI + r16) * 64;
+
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nk) issue(p);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of stage kt have landed once at most the pieces of the one newer stage are outstanding
+        const int newer = issued - 1 - kt;
+        if (NS >= 4 && newer >= 2) {
+            if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (SL - 1)) : "memory");
+        } else if (newer >= 1) {
+            if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL - 1) : "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // everybody's pieces landed AND everybody finished stage kt-1
+        if (issued < nk) issue(buf == 0 ? NS - 1 : buf - 1);   // into the buffer stage kt-1 used
+        const f16 *sb = smem + buf * G144_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 xf[MI], wf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8 *)(sb + xrow + i * 1024 + ck[ks]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[j] = *(const f16x8 *)(sb + wrow + j * 1024 + ck[ks]);
+            if (VAR == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            if (VAR == 1) __builtin_amdgcn_s_setprio(0);
+        }
+        buf = buf == NS - 1 ? 0 : buf + 1;
+    }
+
+    // ---- epilogue: lane owns token m (column r16 of each 16x16 block), registers walk 4 consecutive features --------------
+    const int mb = m0 + wm * 16 * MI, nb = n0 + wn * 16 * NI;
+    if (a.splitk > 1) {
+        float *pb = a.part + (size_t)slice * a.M * a.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mb + 16 * i + r16;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int nn = nb + 16 * j + 4 * kg;
+                if (nn < a.N) *(f32x4 *)(pb + (size_t)m * a.N + nn) = acc[i][j];
+            }
+        }
+        return;
+    }
+    f16x4 bs[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int nn = nb + 16 * j + 4 * kg;
+        bs[j] = (a.bias && nn < a.N) ? *(const f16x4 *)(a.bias + nn) : (f16x4){0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mb + 16 * i + r16;
+        if (m >= a.M) continue;
+        const int bidx = a.rowbias ? m / a.rows_per_batch : 0;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nn = nb + 16 * j + 4 * kg;
+            if (nn >= a.N) continue;
+            f32x4 v = acc[i][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)bs[j][e];
+            if (a.rowbias) {
+                f16x4 b = *(const f16x4 *)(a.rowbias + (size_t)bidx * a.ldrb + nn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+            }
+            if (a.residual) {
+                f16x4 b = *(const f16x4 *)(a.residual + (size_t)m * a.ldr + nn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+            }
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+            *(f16x4 *)(a.out + (size_t)m * a.ldc + nn) = o;
+        }
+    }
+}
+
+// Launch when the problem fits (returns 1): K a multiple of 64 (conv: Cin too), plain epilogue, fp16 in and out.
+// form 0: 6 waves (3 x 2, wave tile 48 x 80); 1: 15 waves (3 x 5, wave tile 48 x 32).
+int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
+{
+    if (a.K % 64 != 0 || (conv && a.Cin % 64 != 0) || a.N % 4 != 0 || a.epi != 0 || a.res32 || a.out32 || a.zins) return 0;
+    if (a.ldc % 4 != 0 || (a.residual && a.ldr % 4 != 0) || (a.rowbias && a.ldrb % 4 != 0)) return 0;
+    a.ntm = cdiv(a.M, G144_BM);
+    a.ntn = cdiv(a.N, G144_BN);
+    int S = (a.splitk > 1 && a.part) ? a.splitk : 1;
+    if (S > a.K / 64) S = a.K / 64;
+    a.splitk = S;
+    const double wbytes = (double)a.N * a.K, xbytes = (double)a.M * (conv ? a.Cin : a.K);
+    a.mfast = wbytes > xbytes ? 1 : 0;
+    static bool attr[16] = {};
+    auto go = [&](auto kern, int which, int threads, int ns) {
+        const size_t lds = (size_t)ns * G144_STAGE * sizeof(f16);
+        if (!attr[which]) {
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr[which] = true;
+        }
+        if (ctx_prof_on()) {
+            hipEvent_t e0, e1;
+            ctx_prof_events(0, &e0, &e1);
+            hipExtLaunchKernelGGL(kern, dim3(a.ntm * a.ntn * S), dim3(threads), lds, s, e0, e1, 0, a);
+        } else
+            hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn * S), dim3(threads), lds, s, a);
+    };
+    switch (form) {
+    case 1: if (conv) go(k_gemm144<3, 5, true, 3, 0>, 3, 960, 3); else go(k_gemm144<3, 5, false, 3, 0>, 2, 960, 3); break;
+    case 2: if (conv) go(k_gemm144<3, 5, true, 4, 0>, 5, 960, 4); else go(k_gemm144<3, 5, false, 4, 0>, 4, 960, 4); break;
+    case 3: if (conv) go(k_gemm144<3, 5, true, 3, 1>, 7, 960, 3); else go(k_gemm144<3, 5, false, 3, 1>, 6, 960, 3); break;
+    case 4: if (conv) go(k_gemm144<3, 5, true, 4, 1>, 9, 960, 4); else go(k_gemm144<3, 5, false, 4, 1>, 8, 960, 4); break;
+    default: if (conv) go(k_gemm144<3, 2, true, 3, 0>, 1, 384, 3); else go(k_gemm144<3, 2, false, 3, 0>, 0, 384, 3); break;
+    }
+    return 1;
+}

@@ -26,7 +26,7 @@ struct GemmArgs {
     float *part;
     int pk;                // K-stage depth chosen by the launcher (32 or 64)
     int krot;              // 1: per-workgroup K rotation (spreads concurrent accesses to shared operand rows)
-    int tile, use8;        // plan: tile id of gemm.hip (-1 = heuristic); use8: -1 heuristic, 0 gemm.hip, 1 gemm8.hip, 2 / 3 conv_halo.hip (128 / 64 features)
+    int tile, use8;        // plan: tile id of gemm.hip (-1 = heuristic); use8: -1 heuristic, 0 gemm.hip, 1 gemm8.hip, 2 / 3 conv_halo.hip (128 / 64 features), 4 / 5 gemm144.hip (6 / 15 waves)
     int stage_epi;         // 1: epilogue staged through LDS (whole-line stores / residual reads)
     int mfast;             // 1: consecutive workgroups walk M first (share the weight panel in their XCD's L2)
 };
@@ -36,6 +36,8 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s);
 int ctx_gemm8_try(GemmArgs &a, bool conv, bool force, hipStream_t s);
 // halo-staged 3x3 convolution (conv_halo.hip), ni = 1 | 2 (64 / 128 features per workgroup): 1 when launched
 int ctx_conv_halo_try(GemmArgs &a, int ni, hipStream_t s);
+// 144x160 kernel (gemm144.hip; plan value use8 = 4: 6 waves, 5: 15 waves): 1 when launched
+int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s);
 // split-K factor the heuristic would use for this problem (1 = none); caller provides a.part = S*M*N floats
 int ctx_gemm_pick_split(int M, int N, int K, int epi);
 // fills a.splitk / a.tile / a.use8 for a fully described problem: the tuned table (gemm_tuned.h) first, heuristics otherwise

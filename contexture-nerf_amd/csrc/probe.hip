@@ -62,3 +62,86 @@ extern "C" int32_t ctx_probe_mfma(int32_t which, const void *A, const void *Bt, 
     CTX_CHECK_LAUNCH("probe");
     return CTX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Staging-rate probe (tools/probe_stage.py): how many bytes per second a CU moves out of L2 by LDS-DMA
+// (global_load_lds_dwordx4), by plain 16-byte loads into registers, or by both at once.  One workgroup per CU, every wave
+// issues U 1-KiB wave-instructions per turn and lets the newest U stay in flight.  Workgroups of one XCD walk a
+// 2 MiB window (L2-resident, larger than L1) in 64 KiB regions.
+typedef const __attribute__((address_space(1))) void *pr_gptr_t;
+typedef __attribute__((address_space(3))) void *pr_lptr_t;
+typedef unsigned int pr_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, int U>
+__global__ __launch_bounds__(1024) void k_probe_stage(const char *__restrict__ src, int iters, unsigned *__restrict__ sink, int shared_region)
+{
+    extern __shared__ __attribute__((aligned(16))) char plds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int region = shared_region ? 0 : ((blockIdx.x >> 3) & 31);
+    const char *base = src + (size_t)region * 65536 + lane * 16;
+    char *dst = plds + wave * (2 * U * 1024);
+    pr_u32x4 acc = {0, 0, 0, 0};
+    pr_u32x4 va[U], vb[U];
+    constexpr int UD = MODE == 0 ? U : (MODE == 1 ? 0 : U / 2);     // DMA pieces per turn; the rest go to registers
+    int off = wave * U * 1024;
+    const int step = nw * U * 1024;
+#pragma unroll
+    for (int i = 0; i < U; ++i) vb[i] = (pr_u32x4){0, 0, 0, 0};
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const char *p = base + ((off + i * 1024) & 65535);
+            if (i < UD) __builtin_amdgcn_global_load_lds((pr_gptr_t)p, (pr_lptr_t)(dst + i * 1024), 16, 0, 0);
+            else va[i] = *(const pr_u32x4 *)p;
+        }
+        off += step;
+#pragma unroll
+        for (int i = UD; i < U; ++i) acc ^= vb[i];
+        if (UD == U) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U) : "memory");
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const char *p = base + ((off + i * 1024) & 65535);
+            if (i < UD) __builtin_amdgcn_global_load_lds((pr_gptr_t)p, (pr_lptr_t)(dst + (U + i) * 1024), 16, 0, 0);
+            else vb[i] = *(const pr_u32x4 *)p;
+        }
+        off += step;
+#pragma unroll
+        for (int i = UD; i < U; ++i) acc ^= va[i];
+        if (UD == U) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U) : "memory");
+    }
+#pragma unroll
+    for (int i = UD; i < U; ++i) acc ^= vb[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u) sink[0] = acc[0];
+}
+
+// mode 0: LDS-DMA only, 1: register loads only, 2: half and half.  Returns milliseconds for `iters` turns (U KiB per wave and turn),
+// negative on error.  src must hold >= 2 MiB.
+extern "C" float ctx_probe_stage(int32_t mode, int32_t waves, int32_t u, int32_t iters, int32_t shared_region, const void *src, void *sink,
+                                 ctx_stream_t stream)
+{
+    if (!src || !sink || waves < 1 || waves > 16 || (u != 4 && u != 8) || mode < 0 || mode > 2 || iters < 2) {
+        ctx_set_error("probe_stage: bad argument");
+        return -1.f;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)waves * 2 * u * 1024;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(64 * waves), lds, s, (const char *)src, 2, (unsigned *)sink, shared_region);
+        (void)hipEventRecord(e0, s);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(64 * waves), lds, s, (const char *)src, iters, (unsigned *)sink, shared_region);
+        (void)hipEventRecord(e1, s);
+    };
+    if (u == 4) { if (mode == 0) go(k_probe_stage<0, 4>); else if (mode == 1) go(k_probe_stage<1, 4>); else go(k_probe_stage<2, 4>); }
+    else { if (mode == 0) go(k_probe_stage<0, 8>); else if (mode == 1) go(k_probe_stage<1, 8>); else go(k_probe_stage<2, 8>); }
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ctx_set_error("probe_stage: %s", hipGetErrorString(e)); return -2.f; }
+    return ms;
+}

@@ -805,8 +805,8 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
 static int check_dims(const ctx_unet *u, int B, int H, int W, int L)
 {
     int div = 1 << (u->cfg.n_levels - 1);
-    if (B < 1 || B > 4 || H < div || W < div || H % div || W % div || L < 1) {
-        ctx_set_error("unet: need 1<=B<=4, H,W multiples of %d, ctx_len>=1 (B=%d H=%d W=%d L=%d)", div, B, H, W, L);
+    if (B < 1 || B > 16 || H < div || W < div || H % div || W % div || L < 1) {
+        ctx_set_error("unet: need 1<=B<=16, H,W multiples of %d, ctx_len>=1 (B=%d H=%d W=%d L=%d)", div, B, H, W, L);
         return CTX_E_ARG;
     }
     return 0;

@@ -324,6 +324,12 @@ void ctx_gemm_tune(int32_t tile, int32_t gemm8);
    which 2: the transposing LDS read ds_read_b64_tr_b16 on an f16 tile A[8][32]; C[64 lanes][4] f32 (Bt unused but non-null). */
 int32_t ctx_probe_mfma(int32_t which, const void *A, const void *Bt, float *C, ctx_stream_t stream);
 
+/* Measurement support (tools/probe_stage.py): bytes per second one workgroup per CU stages out of L2 by LDS-DMA (mode 0), by
+   16-byte register loads (mode 1) or by both (mode 2); `waves` waves per workgroup, `u` (4 | 8) KiB in flight per wave.
+   src >= 2 MiB of device memory, sink >= 4 bytes.  Returns the milliseconds of `iters` turns, negative on error. */
+float ctx_probe_stage(int32_t mode, int32_t waves, int32_t u, int32_t iters, int32_t shared_region, const void *src, void *sink,
+                      ctx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,33 @@ def test_conv_halo_forced(dev, ni, B, H, W, Cin, Cout):
         lib.ctx_gemm_tune(-1, -1)
 
 
+@pytest.mark.parametrize("form", [4, 5])
+def test_gemm144_forced(dev, form):
+    """144x160 kernel, 6- and 15-wave forms (gemm144.hip) forced through the tuning override: whole and ragged tiles, bias + residual, the
+    conv address generator (stride 1 / 2, fused x2 upsample, image borders) and fp32 split-K slabs."""
+    L, lib = _lib()
+    lib.ctx_gemm_tune(-1, form)
+    try:
+        for M, N, K in [(288, 320, 320), (300, 320, 64), (1000, 200, 128), (144, 160, 1344), (1152, 1280, 640), (77, 24, 192)]:
+            test_gemm(dev, M, N, K)
+        for B, H, W, Cin, Cout, stride, ups in [(2, 12, 12, 64, 160, 1, 0), (1, 9, 13, 128, 320, 1, 0), (2, 16, 12, 64, 128, 2, 0),
+                                                 (2, 8, 8, 128, 64, 1, 1), (2, 24, 24, 320, 320, 1, 0)]:
+            test_conv3x3(dev, B, H, W, Cin, Cout, stride, ups)
+        g = torch.Generator().manual_seed(5)
+        for M, N, K, splitk in [(512, 320, 448, 3), (200, 320, 1024, 5), (288, 160, 2048, 16)]:
+            A = torch.randn(M, K, generator=g).half()
+            W = (torch.randn(N, K, generator=g) / K ** 0.5).half(); bias = torch.randn(N, generator=g).half()
+            res = torch.randn(M, N, generator=g).half()
+            out = torch.zeros(M, N, dtype=torch.float16, device=dev)
+            part = torch.empty(splitk * M * N, dtype=torch.float32, device=dev)
+            Ad, Wd, bd, rd = A.to(dev), W.to(dev), bias.to(dev), res.to(dev)
+            ms = lib.ctx_bench_gemm(L.ptr(Ad), L.ptr(Wd), L.ptr(bd), L.ptr(rd), M, N, K, L.ptr(out), 0, 0, 0, 0, 0, 0, L.ptr(part), splitk, 1, L.stream())
+            assert ms > 0, lib.ctx_last_error()
+            _close(out, A.float() @ W.float().T + bias.float() + res.float(), what=f"gemm144 split-K {splitk}")
+    finally:
+        lib.ctx_gemm_tune(-1, -1)
+
+
 @pytest.mark.parametrize("forced", [0, 1])
 @pytest.mark.parametrize("M,C4,K,splitk", [(384, 256, 192, 1), (300, 96, 64, 1), (512, 0, 448, 3), (200, 0, 1024, 5)])
 def test_gemm_geglu_and_splitk(dev, M, C4, K, splitk, forced):

@@ -16,6 +16,8 @@ ap.add_argument("--emit", default="")
 ap.add_argument("--iters", type=int, default=8)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--batch", type=int, default=2, help="UNet batch (2 = CFG pair; 1 = one CFG half per stream)")
+ap.add_argument("--forms", default="", help="comma list of use8 values: time ONLY these kernels (A/B of kernel variants), print all")
+ap.add_argument("--convs", type=int, default=0, help="1: convolution shapes only")
 args = ap.parse_args()
 lib = L.load(); dev = torch.device('cuda:0')
 
@@ -82,6 +84,19 @@ for s_ in shapes:
     if epi == 0 and N % 4 == 0:
         splits += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // 32 // s >= 4 and s * M * N * 4 <= part.numel()]
     cands = []
+    if args.convs and s_[0] == 0:
+        continue
+    if args.forms:
+        best = {}
+        for u8 in [int(v) for v in args.forms.split(",")]:
+            for S in splits:
+                if epi == 0 and K % 64 == 0 and (s_[0] == 0 or Cin % 64 == 0) and (K // 64 // S) >= 1:
+                    t = run(-1, u8, S)
+                    if t and (u8 not in best or t < best[u8][0]): best[u8] = (t, S)
+        lib.ctx_gemm_tune(-1, -1)
+        print(f"{str(s_):42s} " + "  ".join(f"[{u8}] {best[u8][0] * 1e3:7.1f} us S={best[u8][1]}" for u8 in best), flush=True)
+        rows.append((s_, best))
+        continue
     for S in splits:
         for tile in range(27):
             if epi == 1 and tile in (5, 6, 9, 11, 13, 15, 17, 19, 21, 23, 26): continue
@@ -91,6 +106,10 @@ for s_ in shapes:
         if K % 64 == 0 and (s_[0] == 0 or Cin % 64 == 0) and (K // 64 // S) >= 1:
             t = run(-1, 1, S)
             if t: cands.append((t, -1, 1, S))
+        if epi == 0 and K % 64 == 0 and (s_[0] == 0 or Cin % 64 == 0) and (K // 64 // S) >= 1:
+            for u8 in (4, 5):                                   # gemm144.hip: 144x160 tiles, 6 / 15 waves
+                t = run(-1, u8, S)
+                if t: cands.append((t, -1, u8, S))
         if s_[0] == 1 and flags == 0 and H % 16 == 0 and W % 16 == 0 and Cin % 64 == 0 and S <= Cin // 64:
             for u8 in (2, 3):                                   # halo-staged conv, 128 / 64 features per workgroup
                 t = run(-1, u8, S)
@@ -103,6 +122,10 @@ for s_ in shapes:
     print(f"{str(s_):50s} M={M:6d} best {t * 1e3:7.1f} us ({fl / t / 1e9:6.1f} TF) tile={tile} use8={use8} S={S}   | current plan {base * 1e3:7.1f} us | runner-up {cands[1][0] * 1e3:.1f} us {cands[1][1:]}", flush=True)
     rows.append((s_[0], M, N, K, flags, epi, tile, use8, S, t, base))
 lib.ctx_gemm_tune(-1, -1)
+if args.forms:
+    for u8 in [int(v) for v in args.forms.split(",")]:
+        print(f"form {u8}: sum {sum(b[u8][0] for _, b in rows if u8 in b) * 1e3:.0f} us")
+    sys.exit(0)
 print(f"sum best {sum(r[9] for r in rows) * 1e3:.0f} us vs current {sum(r[10] for r in rows) * 1e3:.0f} us (one launch per distinct shape)")
 if args.emit:
     with open(args.emit, "w") as f:
