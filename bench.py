@@ -323,7 +323,7 @@ def main():
             "vae_decode_tflop": round(vae_tflop, 3) if vae_tflop is not None else None,
             "sec_per_view": round((51 * ms_per_step + (vae_ms or 0.0)) / 1e3, 3),
             "sec_per_mesh_6_views_est": round(-(-6 // world) * (51 * ms_per_step + (vae_ms or 0.0)) / 1e3, 3),
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_pipe<...> + k_gemm8 (+ k_splitk_reduce): fp16 MFMA GEMM / implicit-GEMM conv3x3 of the UNet",
+            "roofline": {"bound": "mfma", "kernel": "k_gemm144 + k_gemm_pipe<...> + k_gemm8 (+ k_splitk_reduce): fp16 MFMA GEMM / implicit-GEMM conv3x3 of the UNet",
                          "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": gemm_n, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_n, 1), 2),
                          "flops_per_launch_avg": round(gemm_fl / max(gemm_n, 1) / 1e9, 3), "kernel_ms_per_step": round(gemm_ms, 3)},

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
                 const int b = mm / hw, q = mm - b * hw;
                 const int oy = q / a.Wo, ox = q - oy * a.Wo;
                 xoy[i] = oy * a.stride; xox[i] = ox * a.stride;
-                xoff[i] = b * a.H * a.W * a.Cin;
+                xoff[i] = b * a.H * a.W * a.Cin + xlc[i];
                 pp[i] = g144_zero; pst[i] = 0;
             } else {
                 pp[i] = xok[i] ? a.X + (size_t)m * a.K + (size_t)kbeg * 64 + xlc[i] : g144_zero;
@@ -102,27 +102,30 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             if (wave + NW * i >= 18) continue;
             const int iy = xoy[i] + dy, ix = xox[i] + dx;
             const bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-            pp[i] = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 + xlc[i] : g144_zero;
+            pp[i] = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 : g144_zero;
             pst[i] = ok ? 64 : 0;
         }
         tap_left = (a.Cin - c0) / 64;
     };
-    auto issue = [&](int buf) {
+    auto issue_begin = [&]() {
         if (CONV) {
             if (tap_left == 0) retap();
             --tap_left;
         }
-        f16 *st = smem + buf * G144_STAGE;
-#pragma unroll
-        for (int i = 0; i < SL; ++i) {
-            const int p = wave + NW * i;
-            if (p < NP) {
-                __builtin_amdgcn_global_load_lds((g144_gptr_t)pp[i], (g144_lptr_t)(st + p * 512), 16, 0, 0);
-                pp[i] += pst[i];
-            }
+    };
+    auto issue_slot = [&](int buf, int i) {
+        const int p = wave + NW * i;
+        if (p < NP) {
+            __builtin_amdgcn_global_load_lds((g144_gptr_t)pp[i], (g144_lptr_t)(smem + buf * G144_STAGE + p * 512), 16, 0, 0);
+            pp[i] += pst[i];
         }
-        k_issue += 64;
-        ++issued;
+    };
+    auto issue_end = [&]() { k_issue += 64; ++issued; };
+    auto issue = [&](int buf) {
+        issue_begin();
+#pragma unroll
+        for (int i = 0; i < SL; ++i) issue_slot(buf, i);
+        issue_end();
     };
 
     f32x4 acc[MI][NI];
@@ -138,11 +141,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
         if (p < nk) issue(p);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // this wave's pieces of stage kt have landed once at most the pieces of the one newer stage are outstanding
-        const int newer = issued - 1 - kt;
-        if (NS >= 4 && newer >= 2) {
+    // wait until this wave's pieces of every stage but the `newer` most recent ones have landed
+    auto wait_newer = [&](int newer) {
+        if (newer >= 2) {
             if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SL) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (SL - 1)) : "memory");
         } else if (newer >= 1) {
@@ -150,24 +151,97 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL - 1) : "memory");
         } else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                               // everybody's pieces landed AND everybody finished stage kt-1
-        if (issued < nk) issue(buf == 0 ? NS - 1 : buf - 1);   // into the buffer stage kt-1 used
-        const f16 *sb = smem + buf * G144_STAGE;
+    };
+    int buf = 0;
+    if constexpr (VAR == 0) {
+        // lockstep schedule: one barrier per stage, every wave issues, reads and multiplies in the same order
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_newer(issued - 1 - kt);                            // this wave's pieces of stage kt
+            __builtin_amdgcn_s_barrier();                           // everybody's pieces landed AND everybody finished stage kt-1
+            if (issued < nk) issue(buf == 0 ? NS - 1 : buf - 1);   // into the buffer stage kt-1 used
+            const f16 *sb = smem + buf * G144_STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 xf[MI], wf[NI];
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 xf[MI], wf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8 *)(sb + xrow + i * 1024 + ck[ks]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wf[j] = *(const f16x8 *)(sb + wrow + j * 1024 + ck[ks]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            }
+            buf = buf == NS - 1 ? 0 : buf + 1;
+        }
+    } else {
+        // Software-pipelined schedule (ring of 4).  Measured on the lockstep schedule (each leg removed in turn): a 64-deep stage
+        // costs ~1670 clk, of which DMA, fragment reads and MFMA each expose ~400 and ~390 are fixed: after the barrier every wave
+        // first issues its DMA pieces, then waits for the fragment reads it has just issued, and only then multiplies.  Here the
+        // first half of a stage's fragments (k 0..31) is read during the PREVIOUS stage's last MFMAs, so after the barrier the
+        // MFMAs start at once, and the DMA pieces and the remaining reads ride between them:
+        //   iteration kt:  vmcnt: own pieces of stage kt+1 landed;  lgkmcnt(0): half-fragments A of stage kt are in registers
+        //                  s_barrier  -> everybody's pieces of kt+1 landed, everybody is done reading buffer kt-1
+        //                  MFMA(A) x MI rows, one DMA piece of stage kt+3 (into buffer kt-1) after each row, read B (k 32..63)
+        //                  MFMA(B), read A' (stage kt+1, k 0..31) under them
+        // (Tried first on this tile and dropped, both neutral: two wave groups one barrier apart as in gemm8.hip; whole-stage
+        // register double buffering, which spills at 128 VGPRs.)
+        static_assert(VAR == 0 || NS == 4, "written for a ring of 4");
+        wait_newer(issued - 1);                                     // stage 0 (stages 1, 2 may fly)
+        __builtin_amdgcn_s_barrier();
+        f16x8 xp_[MI], wp_[NI], xq[MI], wq[NI], xb[MI], wb[NI];
+        auto rd = [&](f16x8 (&xf)[MI], f16x8 (&wf)[NI], const f16 *sb, int ks) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8 *)(sb + xrow + i * 1024 + ck[ks]);
 #pragma unroll
             for (int j = 0; j < NI; ++j) wf[j] = *(const f16x8 *)(sb + wrow + j * 1024 + ck[ks]);
-            if (VAR == 1) __builtin_amdgcn_s_setprio(1);
+        };
+        auto mrow = [&](const f16x8 &xf, const f16x8 (&wf)[NI], int i) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf, acc[i][j], 0, 0, 0);
+        };
+        rd(xp_, wp_, smem, 0);
+        // cur = half-fragments A of this stage (loaded), nxt = where the next stage's go
+        auto stage = [&](f16x8 (&xc)[MI], f16x8 (&wc)[NI], f16x8 (&xn)[MI], f16x8 (&wn_)[NI], int kt) {
+            wait_newer(issued - 1 - (kt + 1));                      // own pieces of stage kt+1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // A of this stage has arrived; nothing of stage kt-1 is pending
+            __builtin_amdgcn_s_barrier();
+            const bool go = issued < nk;
+            const int pb = buf == 0 ? NS - 1 : buf - 1;             // buffer of stage kt-1: takes stage kt+3
+            const int nb_ = buf == NS - 1 ? 0 : buf + 1;
+            const f16 *sc = smem + buf * G144_STAGE, *sn = smem + nb_ * G144_STAGE;
+            const bool more = kt + 1 < nk;
+            if (go) issue_begin();
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-            if (VAR == 1) __builtin_amdgcn_s_setprio(0);
+            for (int i = 0; i < MI; ++i) {
+                mrow(xc[i], wc, i);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0) rd(xb, wb, sc, 1);
+                if (go && i < SL) issue_slot(pb, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (go) {
+#pragma unroll
+                for (int i = MI; i < SL; ++i) issue_slot(pb, i);
+                issue_end();
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                mrow(xb[i], wb, i);
+                if (i == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) rd(xn, wn_, sn, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            buf = nb_;
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            stage(xp_, wp_, xq, wq, kt);
+            stage(xq, wq, xp_, wp_, kt + 1);
         }
-        buf = buf == NS - 1 ? 0 : buf + 1;
+        if (kt < nk) stage(xp_, wp_, xq, wq, kt);
     }
 
     // ---- epilogue: lane owns token m (column r16 of each 16x16 block), registers walk 4 consecutive features --------------
@@ -223,7 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
 }
 
 // Launch when the problem fits (returns 1): K a multiple of 64 (conv: Cin too), plain epilogue, fp16 in and out.
-// form 0: 6 waves (3 x 2, wave tile 48 x 80); 1: 15 waves (3 x 5, wave tile 48 x 32).
+// form 0: 6 waves (3 x 2, wave tile 48 x 80); 1: 15 waves (3 x 5, wave tile 48 x 32), lockstep; 2: 15 waves, ring of 4, software-pipelined (MFMAs first, DMA and reads between them).
 int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
 {
     if (a.K % 64 != 0 || (conv && a.Cin % 64 != 0) || a.N % 4 != 0 || a.epi != 0 || a.res32 || a.out32 || a.zins) return 0;
@@ -251,9 +325,7 @@ int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
     };
     switch (form) {
     case 1: if (conv) go(k_gemm144<3, 5, true, 3, 0>, 3, 960, 3); else go(k_gemm144<3, 5, false, 3, 0>, 2, 960, 3); break;
-    case 2: if (conv) go(k_gemm144<3, 5, true, 4, 0>, 5, 960, 4); else go(k_gemm144<3, 5, false, 4, 0>, 4, 960, 4); break;
-    case 3: if (conv) go(k_gemm144<3, 5, true, 3, 1>, 7, 960, 3); else go(k_gemm144<3, 5, false, 3, 1>, 6, 960, 3); break;
-    case 4: if (conv) go(k_gemm144<3, 5, true, 4, 1>, 9, 960, 4); else go(k_gemm144<3, 5, false, 4, 1>, 8, 960, 4); break;
+    case 2: if (conv) go(k_gemm144<3, 5, true, 4, 1>, 5, 960, 4); else go(k_gemm144<3, 5, false, 4, 1>, 4, 960, 4); break;
     default: if (conv) go(k_gemm144<3, 2, true, 3, 0>, 1, 384, 3); else go(k_gemm144<3, 2, false, 3, 0>, 0, 384, 3); break;
     }
     return 1;

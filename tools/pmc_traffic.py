@@ -4,7 +4,7 @@ gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes 
 WRITE_SIZE is taken as is.  Both counters are in KiB.  Usage: pmc_traffic.py FETCH_DIR WRITE_DIR  (prints JSON)"""
 import csv, glob, json, sys, collections
 
-FAM = [("gemm_conv", ("k_gemm_pipe", "k_gemm8", "k_splitk_reduce")), ("attention", ("k_attention",)),
+FAM = [("gemm_conv", ("k_gemm_pipe", "k_gemm8", "k_gemm144", "k_splitk_reduce")), ("attention", ("k_attention",)),
        ("groupnorm", ("k_gn_",)), ("layernorm", ("k_layernorm",)), ("other", ("",))]
 
 
