@@ -260,6 +260,49 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
         }
         return;
     }
+    if (a.stage_epi) {
+        // Through LDS: the accumulator layout gives a lane one token and 4 features, i.e. 8-byte accesses in 32-byte runs over 16
+        // rows per wave instruction, for the store AND for the residual read.  The tile is parked as fp32 [144][164] in the (now
+        // idle) ring and walked back in whole rows: 16 bytes of fp16 per lane, 320-byte row segments, one rounding to fp16.
+        constexpr int RS = G144_BN + 4;
+        float *tile = (float *)smem;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // every wave is done with the ring
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                *(f32x4 *)(tile + (wm * 16 * MI + 16 * i + r16) * RS + wn * 16 * NI + 16 * j + 4 * kg) = acc[i][j];
+        __syncthreads();
+        constexpr int NT = 64 * NW, CPR = G144_BN / 8;              // chunks of 8 features per row
+        for (int ch = tid; ch < G144_BM * CPR; ch += NT) {
+            const int row = ch / CPR, c8 = (ch - row * CPR) * 8;
+            const int m = m0 + row, n = n0 + c8;
+            if (m >= a.M || n >= a.N) continue;
+            const f32x4 v0 = *(const f32x4 *)(tile + row * RS + c8), v1 = *(const f32x4 *)(tile + row * RS + c8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (a.bias) {
+                const f16x8 bb = *(const f16x8 *)(a.bias + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
+            }
+            if (a.rowbias) {
+                const f16x8 bb = *(const f16x8 *)(a.rowbias + (size_t)(m / a.rows_per_batch) * a.ldrb + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
+            }
+            if (a.residual) {
+                const f16x8 bb = *(const f16x8 *)(a.residual + (size_t)m * a.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
+            }
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+            *(f16x8 *)(a.out + (size_t)m * a.ldc + n) = o;
+        }
+        return;
+    }
     f16x4 bs[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -309,6 +352,9 @@ int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
     a.splitk = S;
     const double wbytes = (double)a.N * a.K, xbytes = (double)a.M * (conv ? a.Cin : a.K);
     a.mfast = wbytes > xbytes ? 1 : 0;
+    static int stg = -1;
+    if (stg < 0) { const char *e = getenv("CTX_G144_STAGE"); stg = e ? atoi(e) : 1; }
+    a.stage_epi = stg && form != 0 && a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0);
     static bool attr[16] = {};
     auto go = [&](auto kern, int which, int threads, int ns) {
         const size_t lds = (size_t)ns * G144_STAGE * sizeof(f16);
