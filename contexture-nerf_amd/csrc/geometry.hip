@@ -920,7 +920,7 @@ extern "C" int32_t ctx_raymarch_composite_fwd(const float *raw, const float *z_v
     CTX_REQUIRE(raw && z_vals && rays_d && rgb && disp && acc && depth && R > 0 && S > 0, "raymarch: bad args");
     int64_t nb = cdiv64(R, 4);
     static int cap = -1;
-    if (cap < 0) { const char *e = getenv("CTX_COMPOSITE_BLOCKS"); cap = e ? atoi(e) : 32768; }
+    if (cap < 0) { const char *e = getenv("CTX_COMPOSITE_BLOCKS"); cap = e ? atoi(e) : 262144; }   // one ray per wave up to 1 M rays: 136.8 us vs 142.6 at 32768 blocks (512^2 x 128)
     if (nb > cap) nb = cap;
     hipLaunchKernelGGL(k_composite, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float4 *)raw, z_vals,
                        rays_d, R, S, white_bkgd, rgb, disp, acc, weights, depth);
