@@ -174,6 +174,55 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             }
             buf = buf == NS - 1 ? 0 : buf + 1;
         }
+    } else if constexpr (VAR == 2) {
+        // One barrier per TWO stages (ring of 4 = two pairs of buffers): PMC on the forms above has the waves 42 % of their time at
+        // s_waitcnt / s_barrier with 15 waves meeting every 64 K elements.  Iteration j: the pair's pieces have landed (vmcnt(0):
+        // they were issued one whole iteration ago), barrier, the next pair's pieces go into the buffers pair j-1 just left, one
+        // after each MFMA row, and the four k-32 quarters of the pair are multiplied with the next quarter's fragments read under
+        // the current quarter's MFMAs.
+        static_assert(VAR != 2 || NS == 4, "written for a ring of 4");
+        // (the prologue above has issued stages 0 .. 2; stage 3 follows inside iteration 0)
+        f16x8 xa[MI], wa[NI], xb[MI], wb[NI];
+        auto rd = [&](f16x8 (&xf)[MI], f16x8 (&wf)[NI], const f16 *sb, int ks) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8 *)(sb + xrow + i * 1024 + ck[ks]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[j] = *(const f16x8 *)(sb + wrow + j * 1024 + ck[ks]);
+        };
+        auto mrow = [&](const f16x8 &xf, const f16x8 (&wf)[NI], int i) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf, acc[i][j], 0, 0, 0);
+        };
+        static_assert(SL <= MI, "one DMA piece per MFMA row of a quarter");
+        if (issued < nk) issue(issued & 3);                         // stage 3: the prologue holds two whole pairs
+        for (int k0 = 0; k0 < nk; k0 += 2) {
+            const int b0 = k0 & 3;                                  // buffers of this pair: b0, b0 + 1
+            const bool two = k0 + 1 < nk;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                           // pair landed for everybody; the previous pair's buffers are free
+            // quarter q of the pair: buffer b0 + (q >> 1), k half q & 1
+            rd(xa, wa, smem + b0 * G144_STAGE, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q >= 2 && !two) break;
+                const bool even = (q & 1) == 0;
+                if (q + 1 < (two ? 4 : 2)) {
+                    const f16 *sn = smem + (b0 + ((q + 1) >> 1)) * G144_STAGE;
+                    if (even) rd(xb, wb, sn, (q + 1) & 1); else rd(xa, wa, sn, (q + 1) & 1);
+                }
+                // the next pair's two stages go into the buffers of the previous pair, one stage per even quarter
+                const bool dma = even && issued < nk && issued <= k0 + 3;
+                if (dma) issue_begin();
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    if (even) mrow(xa[i], wa, i); else mrow(xb[i], wb, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dma && i < SL) issue_slot(issued & 3, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (dma) issue_end();
+            }
+        }
     } else {
         // Software-pipelined schedule (ring of 4).  Measured on the lockstep schedule (each leg removed in turn): a 64-deep stage
         // costs ~1670 clk, of which DMA, fragment reads and MFMA each expose ~400 and ~390 are fixed: after the barrier every wave
@@ -340,7 +389,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
 }
 
 // Launch when the problem fits (returns 1): K a multiple of 64 (conv: Cin too), plain epilogue, fp16 in and out.
-// form 0: 6 waves (3 x 2, wave tile 48 x 80); 1: 15 waves (3 x 5, wave tile 48 x 32), lockstep; 2: 15 waves, ring of 4, software-pipelined (MFMAs first, DMA and reads between them).
+// form 0: 6 waves (3 x 2, wave tile 48 x 80); 1: 15 waves (3 x 5, wave tile 48 x 32), lockstep; 2: 15 waves, ring of 4, software-pipelined (MFMAs first, DMA and reads between them); 3: 15 waves, one barrier per two stages.
 int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
 {
     if (a.K % 64 != 0 || (conv && a.Cin % 64 != 0) || a.N % 4 != 0 || a.epi != 0 || a.res32 || a.out32 || a.zins) return 0;
@@ -372,6 +421,7 @@ int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
     switch (form) {
     case 1: if (conv) go(k_gemm144<3, 5, true, 3, 0>, 3, 960, 3); else go(k_gemm144<3, 5, false, 3, 0>, 2, 960, 3); break;
     case 2: if (conv) go(k_gemm144<3, 5, true, 4, 1>, 5, 960, 4); else go(k_gemm144<3, 5, false, 4, 1>, 4, 960, 4); break;
+    case 3: if (conv) go(k_gemm144<3, 5, true, 4, 2>, 7, 960, 4); else go(k_gemm144<3, 5, false, 4, 2>, 6, 960, 4); break;
     default: if (conv) go(k_gemm144<3, 2, true, 3, 0>, 1, 384, 3); else go(k_gemm144<3, 2, false, 3, 0>, 0, 384, 3); break;
     }
     return 1;
