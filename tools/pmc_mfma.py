@@ -7,7 +7,7 @@ the FLOP-derived fractions of the three texture-field kernels (0.82 / 0.77 / 0.8
 SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles per wave (MI355X_MICROARCH.md, PMC units)."""
 import csv, glob, sys, collections
 
-FAM = [("gemm_conv (k_gemm_pipe, k_gemm8, k_splitk_reduce)", ("k_gemm_pipe", "k_gemm8", "k_splitk_reduce")),
+FAM = [("gemm_conv (k_gemm144, k_gemm_pipe, k_gemm8, k_splitk_reduce)", ("k_gemm144", "k_gemm_pipe", "k_gemm8", "k_splitk_reduce")),
        ("attention (k_attention_dma)", ("k_attention",)), ("groupnorm", ("k_gn_",)), ("layernorm", ("k_layernorm",)),
        ("texture field forward (k_uvmlp_fwd)", ("k_uvmlp_fwd",)), ("texture field dgrad (k_uvmlp_dgrad)", ("k_uvmlp_dgrad",)),
        ("texture field wgrad (k_uvmlp_wgrad)", ("k_uvmlp_wgrad",))]
