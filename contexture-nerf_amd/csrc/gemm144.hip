@@ -181,7 +181,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
         // after each MFMA row, and the four k-32 quarters of the pair are multiplied with the next quarter's fragments read under
         // the current quarter's MFMAs.
         static_assert(VAR != 2 || NS == 4, "written for a ring of 4");
-        // (the prologue above has issued stages 0 .. 2; stage 3 follows inside iteration 0)
         f16x8 xa[MI], wa[NI], xb[MI], wb[NI];
         auto rd = [&](f16x8 (&xf)[MI], f16x8 (&wf)[NI], const f16 *sb, int ks) {
 #pragma unroll
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf, acc[i][j], 0, 0, 0);
         };
         static_assert(SL <= MI, "one DMA piece per MFMA row of a quarter");
-        if (issued < nk) issue(issued & 3);                         // stage 3: the prologue holds two whole pairs
+        if (issued < nk) issue(issued & 3);                         // stage 3 (0 .. 2 went above): the prologue holds two whole pairs
         for (int k0 = 0; k0 < nk; k0 += 2) {
             const int b0 = k0 & 3;                                  // buffers of this pair: b0, b0 + 1
             const bool two = k0 + 1 < nk;
