@@ -200,7 +200,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(Attn
         if (AT_NS >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
         else if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        // tile t-1's slot is refilled right after the barrier and the barrier does not wait for LDS reads in flight: the tile's
+        // MFMAs (which wait for their K / V fragments) must all stay above it
+        __builtin_amdgcn_sched_barrier(0);
+        ctx_barrier();
         if (issued < ntiles) issue(slot == 0 ? AT_NS - 1 : slot - 1);          // the slot tile t-1 used
         const f16 *Ks = ring + slot * (2 * 64 * 64);
         attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(Attn
     }
     if (nfull < ntiles) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         const f16 *Ks = ring + slot * (2 * 64 * 64);
         attn_tile<true>(Ks, Ks + 64 * 64, nfull * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
     }

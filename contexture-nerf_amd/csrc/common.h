@@ -35,6 +35,17 @@ typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// s_barrier plus a compiler-level memory fence.  The builtin alone is IntrNoMem to LLVM: LDS reads, LDS-DMA issues and stores may be
+// moved across it at compile time (an LDS read hoisted above the barrier reads a stage other waves' DMA pieces have not landed in
+// yet; seen once the steady-state K loops lost the branches that used to pin the order).  Every workgroup barrier that orders LDS
+// or global traffic between waves goes through this.
+__device__ __forceinline__ void ctx_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll

@@ -125,9 +125,9 @@ __global__ __launch_bounds__(512) void k_conv_halo(GemmArgs a)
     issue_w(1);
     issue_w(2);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WP) : "memory");    // halo of chunk 0 and weight stage 0 (stages 1, 2 may fly)
-    __builtin_amdgcn_s_barrier();
+    ctx_barrier();
     const int grp = wave >> 2;                                   // SIMD partners are waves w and w + 4
-    if (grp == 1) __builtin_amdgcn_s_barrier();                  // stagger: this group runs one barrier behind
+    if (grp == 1) ctx_barrier();                  // stagger: this group runs one barrier behind
 
     // A stage is two barrier-separated sections, R (fragment reads, DMA issue, counted wait) and M (16 MFMAs); the two wave
     // groups alternate, so on every SIMD one wave is in M while its partner is in R.  Slots are refilled two stages after
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(GemmArgs a)
         if (g == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -170,10 +170,10 @@ __global__ __launch_bounds__(512) void k_conv_halo(GemmArgs a)
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();                  // pairs with the stagger barrier of the other group
+    if (grp == 0) ctx_barrier();                  // pairs with the stagger barrier of the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the dummy pieces before the workgroup retires
 
     // ---- epilogue: lane owns one pixel, registers walk 4 consecutive features -------------------------------------------

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
     // K rotation: workgroups that stream the same weight rows (same tile_n) or the same activation rows (same tile_m)
     // start at different K offsets and wrap, so at any instant they hit different cache lines / L2 channels.
     const int k_lo = kbeg * PKT, k_hi = (kbeg + nk) * PKT;
-    const int rot = a.krot ? (int)(((unsigned)tile_m * 13u + (unsigned)tile_n * 5u) % (unsigned)nk) : 0;
+    const int rot = a.krot == 1 ? (int)(((unsigned)tile_m * 13u + (unsigned)tile_n * 5u) % (unsigned)nk) : 0;
     int k_issue = k_lo + rot * PKT, issued = 0, tap_left = 0;
     if (!CONV) {
 #pragma unroll
@@ -317,7 +317,34 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
         if (p < nk) issue(p);
     const int swz = PKT == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7);
     const int xrow = (wm * 32 * MI + r) * PKT, wrow = BM * PKT + (wn * 32 * NI + r) * PKT;
-    for (int kt = 0; kt < nk; kt += NS) {
+    int kt = 0;
+    // steady groups of NS stages: every stage of the group still issues a stage NS-1 ahead, so exactly NS-2 newer stages are in
+    // flight at each wait — none of the wave-uniform branches of the general form below (about ten s_cbranch per stage in the ISA)
+    for (; a.krot == 0 && kt + 2 * NS - 2 < nk; kt += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            // lgkmcnt(0): the barrier does not wait for LDS reads in flight, and the stage issued right after it lands in the
+            // buffer the previous stage's fragments were read from (hipcc sinks those reads' MFMAs below the barrier when it can)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * G) : "memory");
+            ctx_barrier();
+            issue((u + NS - 1) % NS);
+            const f16 *sb = smem + u * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < PKT / 16; ++ks) {
+                const int pch = ((2 * ks + h) ^ swz) * 8;
+                f16x8 xf[MI], wf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8 *)(sb + xrow + i * 32 * PKT + pch);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wf[j] = *(const f16x8 *)(sb + wrow + j * 32 * PKT + pch);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    for (; kt < nk; kt += NS) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             if (kt + u < nk) {
@@ -330,7 +357,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
                 else if (NS >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
                 else if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // see the steady loop
+                ctx_barrier();
                 if (issued < nk) issue((u + NS - 1) % NS);
                 const f16 *sb = smem + u * STAGE;
 #pragma unroll
@@ -369,7 +397,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
     }
     if (a.epi == 0 && a.stage_epi) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring
+        ctx_barrier();                 // every wave is done reading the ring
         gemm_epilogue_staged<MI, NI>(a, acc, m0 + wm * 32 * MI, n0 + wn * 32 * NI, r, h, (float *)smem + wave * (32 * (32 * NI + 4)), lane);
         return;
     }
@@ -432,7 +460,9 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
     static int stg = -1;
     if (stg < 0) { const char *e = getenv("CTX_GEMM_STAGE_EPI"); stg = e ? atoi(e) : 1; }
     a.stage_epi = stg && (a.ldc % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0);
-    a.pk = PKT; a.krot = 0;
+    static int steady = -1;
+    if (steady < 0) { const char *e = getenv("CTX_GEMM_STEADY"); steady = e ? atoi(e) : 1; }
+    a.pk = PKT; a.krot = steady ? 0 : 2;                 // krot = 2: no rotation, general K loop only (A/B switch of the steady loop)
     constexpr int NT = 64 * WM * WN;
     constexpr size_t ring = (size_t)NS * (BM + BN) * PKT * sizeof(f16);
     constexpr size_t patch = (size_t)WM * WN * 32 * (32 * NI + 4) * sizeof(float);

@@ -20,6 +20,7 @@
 #include "kernels.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <type_traits>
 
 typedef const __attribute__((address_space(1))) void *g144_gptr_t;
 typedef __attribute__((address_space(3))) void *g144_lptr_t;
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
         // lockstep schedule: one barrier per stage, every wave issues, reads and multiplies in the same order
         for (int kt = 0; kt < nk; ++kt) {
             wait_newer(issued - 1 - kt);                            // this wave's pieces of stage kt
-            __builtin_amdgcn_s_barrier();                           // everybody's pieces landed AND everybody finished stage kt-1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the barrier does not wait for LDS reads in flight (stage kt-1's)
+            ctx_barrier();                                          // everybody's pieces landed AND everybody finished stage kt-1
             if (issued < nk) issue(buf == 0 ? NS - 1 : buf - 1);   // into the buffer stage kt-1 used
             const f16 *sb = smem + buf * G144_STAGE;
 #pragma unroll
@@ -194,11 +196,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
         };
         static_assert(SL <= MI, "one DMA piece per MFMA row of a quarter");
         if (issued < nk) issue(issued & 3);                         // stage 3 (0 .. 2 went above): the prologue holds two whole pairs
-        for (int k0 = 0; k0 < nk; k0 += 2) {
+        // `steady`: a whole pair with both of the next pair's stages still to issue: no wave-uniform branches in the body
+        auto pair = [&](int k0, auto steady) {
+            constexpr bool ST = decltype(steady)::value;
             const int b0 = k0 & 3;                                  // buffers of this pair: b0, b0 + 1
-            const bool two = k0 + 1 < nk;
+            const bool two = ST || k0 + 1 < nk;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                           // pair landed for everybody; the previous pair's buffers are free
+            ctx_barrier();                           // pair landed for everybody; the previous pair's buffers are free
             // quarter q of the pair: buffer b0 + (q >> 1), k half q & 1
             rd(xa, wa, smem + b0 * G144_STAGE, 0);
 #pragma unroll
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
                     if (even) rd(xb, wb, sn, (q + 1) & 1); else rd(xa, wa, sn, (q + 1) & 1);
                 }
                 // the next pair's two stages go into the buffers of the previous pair, one stage per even quarter
-                const bool dma = even && issued < nk && issued <= k0 + 3;
+                const bool dma = even && (ST || (issued < nk && issued <= k0 + 3));
                 if (dma) issue_begin();
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
@@ -221,7 +225,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
                 }
                 if (dma) issue_end();
             }
-        }
+        };
+        using T1 = std::integral_constant<bool, true>;
+        using T0 = std::integral_constant<bool, false>;
+        int k0 = 0;
+        if (k0 < nk) { pair(k0, T0{}); k0 += 2; }                   // pair 0: the next pair was issued by the prologue
+        for (; k0 + 3 < nk; k0 += 2) pair(k0, T1{});                // stages k0 + 2, k0 + 3 exist and are issued here
+        for (; k0 < nk; k0 += 2) pair(k0, T0{});
     } else {
         // Software-pipelined schedule (ring of 4).  Measured on the lockstep schedule (each leg removed in turn): a 64-deep stage
         // costs ~1670 clk, of which DMA, fragment reads and MFMA each expose ~400 and ~390 are fixed: after the barrier every wave
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
         // register double buffering, which spills at 128 VGPRs.)
         static_assert(VAR == 0 || NS == 4, "written for a ring of 4");
         wait_newer(issued - 1);                                     // stage 0 (stages 1, 2 may fly)
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         f16x8 xp_[MI], wp_[NI], xq[MI], wq[NI], xb[MI], wb[NI];
         auto rd = [&](f16x8 (&xf)[MI], f16x8 (&wf)[NI], const f16 *sb, int ks) {
 #pragma unroll
@@ -250,15 +260,23 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
         };
         rd(xp_, wp_, smem, 0);
         // cur = half-fragments A of this stage (loaded), nxt = where the next stage's go
-        auto stage = [&](f16x8 (&xc)[MI], f16x8 (&wc)[NI], f16x8 (&xn)[MI], f16x8 (&wn_)[NI], int kt) {
-            wait_newer(issued - 1 - (kt + 1));                      // own pieces of stage kt+1
+        // `steady` (a std::integral_constant): the loop's middle, where a stage is still to be issued (go), a next stage exists
+        // (more) and exactly one newer stage is in flight at the wait — none of the wave-uniform branches those conditions cost
+        // in the general form (ten s_cbranch per stage in the ISA), only the wave's own piece count remains
+        auto stage = [&](f16x8 (&xc)[MI], f16x8 (&wc)[NI], f16x8 (&xn)[MI], f16x8 (&wn_)[NI], int kt, auto steady) {
+            constexpr bool ST = decltype(steady)::value;
+            if (ST) {
+                if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL - 1) : "memory");
+            } else
+                wait_newer(issued - 1 - (kt + 1));                  // own pieces of stage kt+1
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // A of this stage has arrived; nothing of stage kt-1 is pending
-            __builtin_amdgcn_s_barrier();
-            const bool go = issued < nk;
+            ctx_barrier();
+            const bool go = ST || issued < nk;
             const int pb = buf == 0 ? NS - 1 : buf - 1;             // buffer of stage kt-1: takes stage kt+3
             const int nb_ = buf == NS - 1 ? 0 : buf + 1;
             const f16 *sc = smem + buf * G144_STAGE, *sn = smem + nb_ * G144_STAGE;
-            const bool more = kt + 1 < nk;
+            const bool more = ST || kt + 1 < nk;
             if (go) issue_begin();
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -284,12 +302,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             }
             buf = nb_;
         };
+        using T1 = std::integral_constant<bool, true>;
+        using T0 = std::integral_constant<bool, false>;
         int kt = 0;
-        for (; kt + 1 < nk; kt += 2) {
-            stage(xp_, wp_, xq, wq, kt);
-            stage(xq, wq, xp_, wp_, kt + 1);
+        // steady pairs: stages kt and kt+1 both issue a stage (kt + 4 < nk) ...
+        for (; kt + 4 < nk; kt += 2) {
+            stage(xp_, wp_, xq, wq, kt, T1{});
+            stage(xq, wq, xp_, wp_, kt + 1, T1{});
         }
-        if (kt < nk) stage(xp_, wp_, xq, wq, kt);
+        // ... then the last (up to four) stages in the general form
+        for (; kt + 1 < nk; kt += 2) {
+            stage(xp_, wp_, xq, wq, kt, T0{});
+            stage(xq, wq, xp_, wp_, kt + 1, T0{});
+        }
+        if (kt < nk) stage(xp_, wp_, xq, wq, kt, T0{});
     }
 
     // ---- epilogue: lane owns token m (column r16 of each 16x16 block), registers walk 4 consecutive features --------------
@@ -315,7 +341,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
         constexpr int RS = G144_BN + 4;
         float *tile = (float *)smem;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                               // every wave is done with the ring
+        ctx_barrier();                               // every wave is done with the ring
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll

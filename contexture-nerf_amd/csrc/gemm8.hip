@@ -30,6 +30,7 @@
 #include "kernels.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <type_traits>
 
 typedef const __attribute__((address_space(1))) void *g8_gptr_t;
 typedef __attribute__((address_space(3))) void *g8_lptr_t;
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
 
     int issued = 0;                                                 // half-tiles issued so far
     // issue half-tile `issued` (kind = issued & 3, K-tile = issued >> 2) if it exists
-    auto issue = [&](const int kind) {
-        if (issued >= nht) return;
+    auto issue = [&](const int kind, const bool steady = false) {
+        if (!steady && issued >= nht) return;
         const int t = issued >> 2;
         const int slot = kind == 0 ? 0 : (kind == 3 ? 1 : (kind == 1 ? 2 : 3));      // LDS order X0 X1 W0 W1
         f16 *dst = smem + (t & 1) * 32768 + slot * 8192;
@@ -161,11 +162,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
     // ---- prologue: X0 W0 W1 X1 of tile 0, X0 W0 of tile 1 ---------------------------------------------------------------
     issue(0); issue(1); issue(2); issue(3); issue(0); issue(1);
     { const int n = issued - 1 - 1; G8_WAIT(n); }                  // tile 0's X0, W0 (half-tiles 0, 1)
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();                     // stagger: this group runs one barrier behind
+    ctx_barrier();
+    if (wr == 1) ctx_barrier();                     // stagger: this group runs one barrier behind
 
     f16x8 xf[4][2], wf0[2][2], wf1[2][2];
-    for (int t = 0; t < nkt; ++t) {
+    // `steady` (std::integral_constant): K-tiles during which every half-tile issue still exists and four half-tiles are in flight at
+    // every wait: the counted waits are one immediate and the issues unconditional (the general form costs a dozen s_cbranch per tile)
+    auto ktile = [&](const int t, auto steady) {
+        constexpr bool ST = decltype(steady)::value;
         const f16 *sb = smem + (t & 1) * 32768;
         const f16 *X0 = sb + xrow, *X1 = sb + 8192 + xrow, *W0 = sb + 16384 + wrow, *W1 = sb + 24576 + wrow;
         // ---- phase 0: (X0, W0) ------------------------------------------------------------------------------------
@@ -173,10 +177,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
         for (int j = 0; j < 2; ++j) { wf0[j][0] = *(const f16x8 *)(W0 + j * 1024 + ck0); wf0[j][1] = *(const f16x8 *)(W0 + j * 1024 + ck1); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { xf[j][0] = *(const f16x8 *)(X0 + j * 1024 + ck0); xf[j][1] = *(const f16x8 *)(X0 + j * 1024 + ck1); }
-        issue(2);                                                   // W1(t+1)
-        { const int n = issued - 1 - (4 * t + 2); G8_WAIT(n); }     // W1(t) for phase 1
+        issue(2, ST);                                               // W1(t+1)
+        { const int n = issued - 1 - (4 * t + 2); if (ST) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else G8_WAIT(n); }     // W1(t) for phase 1
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -187,15 +191,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[j][ks], xf[i][ks], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 1: (X0, W1) ------------------------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < 2; ++j) { wf1[j][0] = *(const f16x8 *)(W1 + j * 1024 + ck0); wf1[j][1] = *(const f16x8 *)(W1 + j * 1024 + ck1); }
-        issue(3);                                                   // X1(t+1)
-        { const int n = issued - 1 - (4 * t + 3); G8_WAIT(n); }     // X1(t) for phase 2
+        issue(3, ST);                                               // X1(t+1)
+        { const int n = issued - 1 - (4 * t + 3); if (ST) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else G8_WAIT(n); }     // X1(t) for phase 2
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -206,14 +210,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
                 for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[j][ks], xf[i][ks], acc[i][2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 2: (X1, W1) ------------------------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < 4; ++j) { xf[j][0] = *(const f16x8 *)(X1 + j * 1024 + ck0); xf[j][1] = *(const f16x8 *)(X1 + j * 1024 + ck1); }
-        issue(0);                                                   // X0(t+2)
+        issue(0, ST);                                               // X0(t+2)
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -224,13 +228,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
                 for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[j][ks], xf[i][ks], acc[4 + i][2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 3: (X1, W0) ------------------------------------------------------------------------------------
-        issue(1);                                                   // W0(t+2)
-        { const int n = issued - 1 - (4 * t + 5); G8_WAIT(n); }     // X0, W0 of tile t+1 for its phase 0
+        issue(1, ST);                                               // W0(t+2)
+        { const int n = issued - 1 - (4 * t + 5); if (ST) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else G8_WAIT(n); }     // X0, W0 of tile t+1 for its phase 0
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -241,10 +245,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
                 for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0[j][ks], xf[i][ks], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ctx_barrier();
         __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+        using T1 = std::integral_constant<bool, true>;
+        using T0 = std::integral_constant<bool, false>;
+        int t = 0;
+        for (; t + 2 < nkt; ++t) ktile(t, T1{});
+        for (; t < nkt; ++t) ktile(t, T0{});
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();                     // pairs with the stagger barrier of the other group
+    if (wr == 0) ctx_barrier();                     // pairs with the stagger barrier of the other group
 
     // ---- epilogue: lane owns token m (column r16 of each 16x16 block), registers walk 4 consecutive features --------------
     const int mb = m0 + wr * 128, nb = n0 + wc * 64;

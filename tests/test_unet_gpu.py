@@ -151,6 +151,30 @@ def test_gemm144_forced(dev, form):
         lib.ctx_gemm_tune(-1, -1)
 
 
+def test_gemm_kernels_repeat_without_races(dev):
+    """Race screen (short form of tools/stress_gemm.py): the kernels whose K loops keep DMA in flight across barriers, several
+    workgroups per CU, five launches each on one UNet-sized problem; an early LDS read or refill shows as a few hundred wrong
+    elements in some launches only."""
+    L, lib = _lib()
+    g = torch.Generator(device=dev).manual_seed(3)
+    M, N, K = 4608, 640, 640
+    x = torch.randn(M, K, generator=g, device=dev).half(); w = (torch.randn(N, K, generator=g, device=dev) / K ** 0.5).half()
+    b = torch.randn(N, generator=g, device=dev).half(); r = torch.randn(M, N, generator=g, device=dev).half()
+    want = x.float() @ w.float().T + b.float() + r.float()
+    part = torch.empty(2 * M * N, dtype=torch.float32, device=dev)
+    try:
+        for tile, u8 in [(5, 0), (14, 0), (15, 0), (19, 0), (20, 0), (25, 0), (-1, 1), (-1, 5), (-1, 6), (-1, 7)]:
+            for S in (1, 2):
+                lib.ctx_gemm_tune(tile, u8)
+                for rep in range(5):
+                    y = torch.zeros(M, N, dtype=torch.float16, device=dev)
+                    ms = lib.ctx_bench_gemm(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(r), M, N, K, L.ptr(y), 0, 0, 0, 0, 0, 0, L.ptr(part), S, 1, L.stream())
+                    assert ms > 0, lib.ctx_last_error()
+                    _close(y, want, rtol=3e-3, atol=4e-3, what=f"tile {tile} use8 {u8} split {S} launch {rep}")
+    finally:
+        lib.ctx_gemm_tune(-1, -1)
+
+
 @pytest.mark.parametrize("forced", [0, 1])
 @pytest.mark.parametrize("M,C4,K,splitk", [(384, 256, 192, 1), (300, 96, 64, 1), (512, 0, 448, 3), (200, 0, 1024, 5)])
 def test_gemm_geglu_and_splitk(dev, M, C4, K, splitk, forced):
