@@ -195,7 +195,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(Attn
     // the accumulators keep one fixed register block (unrolled / two-variant bodies made hipcc shuffle all 48 of them)
     const int nfull = a.Skv / AT_KB;
     int slot = 0;
-    for (int t = 0; t < nfull; ++t) {
+    int t = 0;
+    // steady tiles: a tile AT_NS-1 ahead is still to be issued, so exactly AT_NS-2 newer tiles are in flight at the wait (no
+    // wave-uniform branches in the body)
+    for (; t < nfull && t + AT_NS - 1 < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AT_NS - 2) * G) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ctx_barrier();
+        issue(slot == 0 ? AT_NS - 1 : slot - 1);
+        const f16 *Ks = ring + slot * (2 * 64 * 64);
+        attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
+        slot = slot + 1 == AT_NS ? 0 : slot + 1;
+    }
+    for (; t < nfull; ++t) {
         const int newer = issued - 1 - t;
         if (AT_NS >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
         else if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
