@@ -124,7 +124,7 @@ template <int AT_NS, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) f16 ring[AT_NS * 2 * 64 * 64];    // per stage: K [64][64] then V^T [64][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: SGPR, scalar branches
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hd = blockIdx.y;
     const int q0 = blockIdx.x * (32 * NW) + wave * 32;

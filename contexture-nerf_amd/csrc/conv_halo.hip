@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512) void k_conv_halo(GemmArgs a)
     f16 *wring = smem + 2 * HALO;
     f16 *scratch = wring + 4 * WST;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: SGPR, scalar branches
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 

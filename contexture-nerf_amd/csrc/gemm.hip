@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_pipe(GemmArgs a)
     constexpr int STAGE = (BM + BN) * PKT;           // f16 per stage
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: SGPR, scalar branches
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     // 1-D grid of tiles x K-slices, slice-major, cut into 8 contiguous runs (one per XCD: blocks b and b+8 share an L2):

@@ -36,7 +36,9 @@ __device__ __forceinline__ int g144_xcd_remap(int bid, int nwg)
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int WM, int WN, bool CONV, int NS, int VAR>
+// UPS: the convolution has the fused nearest x2 upsample (generic per-tap address arithmetic); without it a tap is one scalar
+// offset from the lane's centre-tap pointer and a bit of a 9-bit in-bounds mask
+template <int WM, int WN, bool CONV, int NS, int VAR, bool UPS = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
 {
     constexpr int NW = WM * WN, MI = 9 / WM, NI = 10 / WN;          // waves; 16x16 blocks per wave along tokens / features
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
     constexpr int SL = (NP + NW - 1) / NW;                          // piece slots per wave (the last one empty on some waves)
     static_assert(9 % WM == 0 && 10 % WN == 0, "wave grid must divide 9 x 10 blocks");
     extern __shared__ __attribute__((aligned(16))) f16 smem[];     // [NS][144 X rows | 160 W rows][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: SGPR, scalar branches
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, kg = lane >> 4;
 
@@ -59,9 +61,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
 
     // ---- DMA state: piece p = wave + NW i of the stage image; p < 18 activation rows 8p.., else weight rows 8(p-18).. -----
     const int prow = lane >> 3, pc = lane & 7;
-    const f16 *pp[SL];
-    int pst[SL], xoff[SL], xoy[SL], xox[SL], xlc[SL];
+    constexpr bool FAST = CONV && !UPS;
+    const f16 *pp[SL], *xcen[SL];
+    int pst[SL], xoff[SL], xoy[SL], xox[SL], xlc[SL], xval[SL];
     bool xok[SL];
+    const f16 *const zp = g144_zero;
     const bool full = wave + NW * (SL - 1) < NP;                    // this wave uses its last slot
 #pragma unroll
     for (int i = 0; i < SL; ++i) {
@@ -80,7 +84,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
                 const int oy = q / a.Wo, ox = q - oy * a.Wo;
                 xoy[i] = oy * a.stride; xox[i] = ox * a.stride;
                 xoff[i] = b * a.H * a.W * a.Cin + xlc[i];
-                pp[i] = g144_zero; pst[i] = 0;
+                pp[i] = zp; pst[i] = 0;
+                if (FAST) {
+                    xcen[i] = a.X + (size_t)xoff[i] + (size_t)(xoy[i] * a.W + xox[i]) * a.Cin;
+                    int v = 0;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int iy = xoy[i] + t / 3 - 1 + a.poff, ix = xox[i] + t % 3 - 1 + a.poff;
+                        if (xok[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v |= 1 << t;
+                    }
+                    xval[i] = v;
+                }
             } else {
                 pp[i] = xok[i] ? a.X + (size_t)m * a.K + (size_t)kbeg * 64 + xlc[i] : g144_zero;
                 pst[i] = xok[i] ? 64 : 0;
@@ -94,7 +108,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
     }
 
     int k_issue = kbeg * 64, issued = 0, tap_left = 0;
+    int cur_tap = CONV ? (kbeg * 64) / a.Cin : 0, cur_c0 = CONV ? kbeg * 64 - cur_tap * a.Cin : 0;   // FAST: tap and first channel of the next stage
     auto retap = [&]() {                                            // CONV: new 3x3 tap -> recompute the activation pointers
+        if (FAST) {
+            const int dy = cur_tap / 3 - 1 + a.poff, dx = cur_tap - (cur_tap / 3) * 3 - 1 + a.poff;
+            const int soff = (dy * a.W + dx) * a.Cin + cur_c0;     // scalar: the same for every lane
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                if (wave + NW * i >= 18) continue;
+                const bool v = (xval[i] >> cur_tap) & 1;
+                pp[i] = v ? xcen[i] + soff : zp;
+                pst[i] = v ? 64 : 0;
+            }
+            tap_left = (a.Cin - cur_c0) >> 6;
+            return;
+        }
         const int tap = k_issue / a.Cin, c0 = k_issue - tap * a.Cin;
         const int dy = tap / 3 - 1 + a.poff, dx = tap % 3 - 1 + a.poff;
         const int Hv = a.H << a.ups, Wv = a.W << a.ups;
@@ -103,7 +131,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             if (wave + NW * i >= 18) continue;
             const int iy = xoy[i] + dy, ix = xox[i] + dx;
             const bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-            pp[i] = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 : g144_zero;
+            pp[i] = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 : zp;
             pst[i] = ok ? 64 : 0;
         }
         tap_left = (a.Cin - c0) / 64;
@@ -121,7 +149,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             pp[i] += pst[i];
         }
     };
-    auto issue_end = [&]() { k_issue += 64; ++issued; };
+    auto issue_end = [&]() {
+        k_issue += 64; ++issued;
+        if (FAST) { cur_c0 += 64; if (cur_c0 == a.Cin) { cur_c0 = 0; ++cur_tap; } }
+    };
     auto issue = [&](int buf) {
         issue_begin();
 #pragma unroll
@@ -443,11 +474,24 @@ int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
         } else
             hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn * S), dim3(threads), lds, s, a);
     };
+    const bool ups = conv && a.ups;
     switch (form) {
-    case 1: if (conv) go(k_gemm144<3, 5, true, 3, 0>, 3, 960, 3); else go(k_gemm144<3, 5, false, 3, 0>, 2, 960, 3); break;
-    case 2: if (conv) go(k_gemm144<3, 5, true, 4, 1>, 5, 960, 4); else go(k_gemm144<3, 5, false, 4, 1>, 4, 960, 4); break;
-    case 3: if (conv) go(k_gemm144<3, 5, true, 4, 2>, 7, 960, 4); else go(k_gemm144<3, 5, false, 4, 2>, 6, 960, 4); break;
-    default: if (conv) go(k_gemm144<3, 2, true, 3, 0>, 1, 384, 3); else go(k_gemm144<3, 2, false, 3, 0>, 0, 384, 3); break;
+    case 1:
+        if (!conv) go(k_gemm144<3, 5, false, 3, 0>, 2, 960, 3);
+        else if (ups) go(k_gemm144<3, 5, true, 3, 0, true>, 8, 960, 3); else go(k_gemm144<3, 5, true, 3, 0>, 3, 960, 3);
+        break;
+    case 2:
+        if (!conv) go(k_gemm144<3, 5, false, 4, 1>, 4, 960, 4);
+        else if (ups) go(k_gemm144<3, 5, true, 4, 1, true>, 9, 960, 4); else go(k_gemm144<3, 5, true, 4, 1>, 5, 960, 4);
+        break;
+    case 3:
+        if (!conv) go(k_gemm144<3, 5, false, 4, 2>, 6, 960, 4);
+        else if (ups) go(k_gemm144<3, 5, true, 4, 2, true>, 10, 960, 4); else go(k_gemm144<3, 5, true, 4, 2>, 7, 960, 4);
+        break;
+    default:
+        if (!conv) go(k_gemm144<3, 2, false, 3, 0>, 0, 384, 3);
+        else if (ups) go(k_gemm144<3, 2, true, 3, 0, true>, 11, 384, 3); else go(k_gemm144<3, 2, true, 3, 0>, 1, 384, 3);
+        break;
     }
     return 1;
 }

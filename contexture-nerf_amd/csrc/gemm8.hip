@@ -65,7 +65,7 @@ template <bool CONV>
 __global__ __launch_bounds__(512, 2) void k_gemm8(GemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) f16 smem[];     // [2 K-tiles][X0 X1 W0 W1][128 rows][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: SGPR, scalar branches
     const int wr = wave >> 2, wc = wave & 3;
     const int r16 = lane & 15, kg = lane >> 4;
 
