@@ -556,62 +556,84 @@ int ctx_time_embed_f16(const float *t, int B, int dim, f16 *out, hipStream_t s)
 // conv_in: sample [B,Cin,H,W] f32 NCHW (Cin <= 8) -> y [B,H,W,Cout] f16, 3x3 pad 1.  w packed [Cout][3][3][8] f16.
 // One pixel per lane: its 9 x Cin inputs live in registers; the weights of this block's slice of output channels
 // sit in LDS and are read as wave-wide broadcasts; grid.y splits the output channels.
-#define CI_SPLIT 4
-// CP = padded input channels of the weight pack [Cout][3][3][CP]: 8 (latents + depth, VAE) or 16 (the 9-channel inpainting UNet)
-template <int CP>
+#define CI_SPLIT 16
+// CP = padded input channels of the weight pack [Cout][3][3][CP]: 8 (latents + depth, VAE) or 16 (the 9-channel inpainting UNet);
+// CX = channels actually multiplied (the pack's zero padding is skipped).  The block's weight slice is converted to fp32 once
+// when it is staged (the kernel is VALU-bound: one cvt per FMA otherwise).
+template <int CP, int CX>
 __global__ __launch_bounds__(256) void k_conv_in(const float *__restrict__ x, const f16 *__restrict__ w,
                                                  const f16 *__restrict__ bias, int B, int Cin, int H, int W, int Cout,
                                                  f16 *__restrict__ y)
 {
-    extern __shared__ __attribute__((aligned(16))) f16 s_w[];     // [o_per][9 * CP]
-    constexpr int WR = 9 * CP;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // [o_per * 8][9][CX]
+    constexpr int WR = 9 * CP, WX = 9 * CX;
     const int o8n = Cout / 8;
     const int o8_per = (o8n + CI_SPLIT - 1) / CI_SPLIT;
     const int o8_0 = blockIdx.y * o8_per, o8_1 = min(o8n, o8_0 + o8_per);
-    const int nw = (o8_1 - o8_0) * 8 * WR;
-    for (int i = threadIdx.x; i < nw; i += 256) s_w[i] = w[(size_t)o8_0 * 8 * WR + i];
+    const int no = (o8_1 - o8_0) * 8;
+    for (int i = threadIdx.x; i < no * WX; i += 256) {
+        const int o = i / WX, r = i - o * WX, t = r / CX, c = r - t * CX;
+        s_w[i] = (float)w[(size_t)(o8_0 * 8 + o) * WR + t * CP + c];
+    }
     __syncthreads();
     const int64_t npix = (int64_t)B * H * W;
-    int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (pix >= npix) return;
-    int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
+    const int64_t pix0 = (int64_t)blockIdx.x * 256;
+    const int64_t pix = pix0 + threadIdx.x;
+    const bool live = pix < npix;
+    const int64_t pq = live ? pix : npix - 1;
+    int b = (int)(pq / (H * W)), p = (int)(pq % (H * W));
     int oy = p / W, ox = p % W;
-    float in[9][CP];
+    float in[9][CX];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
         bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
-        for (int c = 0; c < CP; ++c)
+        for (int c = 0; c < CX; ++c)
             in[t][c] = (ok && c < Cin) ? (float)(f16)x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
     }
-    for (int o8 = o8_0; o8 < o8_1; ++o8) {
-        f16x8 o;
+    // A lane's 8 channels are 16 bytes of a pixel row that is Cout x 2 bytes long: stored directly that is one 16-byte piece
+    // per cache line and instruction (the kernel was bound by those stores: 53 us for 11.8 MB at 96^2 x 320).  Eight channel
+    // groups at a time go through an LDS patch [256 pixels][64 channels] and leave as 128-byte row segments.
+    f16 *patch = (f16 *)(s_w + no * WX);
+    for (int g0 = o8_0; g0 < o8_1; g0 += 8) {
+        const int ng = min(8, o8_1 - g0);
+        for (int gi = 0; gi < ng; ++gi) {
+            const int o8 = g0 + gi;
+            f16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f16 *wr = s_w + ((o8 - o8_0) * 8 + j) * WR;
-            float acc = (float)bias[o8 * 8 + j];
+            for (int j = 0; j < 8; ++j) {
+                const float *wr = s_w + ((o8 - o8_0) * 8 + j) * WX;
+                float acc = (float)bias[o8 * 8 + j];
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+                for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int c8 = 0; c8 < CP; c8 += 8) {
-                    f16x8 wv = *(const f16x8 *)(wr + t * CP + c8);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) acc += in[t][c8 + c] * (float)wv[c];
-                }
-            o[j] = (f16)acc;
+                    for (int c = 0; c < CX; ++c) acc += in[t][c] * wr[t * CX + c];
+                o[j] = (f16)acc;
+            }
+            *(f16x8 *)(patch + threadIdx.x * 72 + gi * 8) = o;      // row stride 72 f16 = 144 B: conflict-free 16-byte writes
         }
-        *(f16x8 *)(y + pix * Cout + o8 * 8) = o;
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < 256 * ng; ch += 256) {
+            const int px = ch / ng, gi = ch - px * ng;
+            if (pix0 + px < npix) *(f16x8 *)(y + (pix0 + px) * Cout + (g0 + gi) * 8) = *(const f16x8 *)(patch + px * 72 + gi * 8);
+        }
+        __syncthreads();
     }
 }
 int ctx_conv_in_f16(const float *x, const f16 *w, const f16 *bias, int B, int Cin, int H, int W, int Cout, f16 *y, hipStream_t s)
 {
     int64_t npix = (int64_t)B * H * W;
     int o8_per = (Cout / 8 + CI_SPLIT - 1) / CI_SPLIT;
-    if (Cin <= 8)
-        hipLaunchKernelGGL(k_conv_in<8>, dim3((unsigned)cdiv64(npix, 256), CI_SPLIT), dim3(256), (size_t)o8_per * 8 * 72 * 2, s, x, w, bias, B, Cin, H, W, Cout, y);
-    else
-        hipLaunchKernelGGL(k_conv_in<16>, dim3((unsigned)cdiv64(npix, 256), CI_SPLIT), dim3(256), (size_t)o8_per * 8 * 144 * 2, s, x, w, bias, B, Cin, H, W, Cout, y);
+    const dim3 grid((unsigned)cdiv64(npix, 256), CI_SPLIT);
+#define CI_GO(CP_, CX_) hipLaunchKernelGGL((k_conv_in<CP_, CX_>), grid, dim3(256), (size_t)o8_per * 8 * 9 * CX_ * sizeof(float) + 256 * 72 * sizeof(f16), s, x, w, bias, B, Cin, H, W, Cout, y)
+    if (Cin <= 3) CI_GO(8, 3);
+    else if (Cin == 4) CI_GO(8, 4);
+    else if (Cin == 5) CI_GO(8, 5);
+    else if (Cin <= 8) CI_GO(8, 8);
+    else if (Cin == 9) CI_GO(16, 9);
+    else CI_GO(16, 16);
+#undef CI_GO
     return CTX_OK;
 }
 
@@ -619,14 +641,26 @@ int ctx_conv_in_f16(const float *x, const f16 *w, const f16 *bias, int B, int Ci
 // w packed [Cout][3][3][C] f16, staged in LDS once per block.  One wave per output pixel: the 9 taps x C/8 16-byte chunks
 // of the pixel's neighbourhood are one flat item list dealt over the 64 lanes (all lanes busy for any C), every load of a
 // lane issued (unconditionally, clamped) before the first use; the Cout sums are DPP wave reductions.
-template <int NU>
+// WF32: the staged weights are converted to fp32 once (the kernel is VALU-bound: 40 cvt per 32 FMA otherwise); used when the
+// fp32 copy fits 64 KiB of LDS
+template <int NU, bool WF32>
 __global__ __launch_bounds__(256) void k_conv_out(const f16 *__restrict__ x, const f16 *__restrict__ w,
                                                   const f16 *__restrict__ bias, int B, int H, int W, int C, int Cout,
                                                   float *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) f16 s_cw[];     // [Cout][9][C]
+    extern __shared__ __attribute__((aligned(16))) char s_cw_raw[];    // [Cout][9][C] f16 or fp32
+    f16 *s_cw = (f16 *)s_cw_raw;
+    float *s_cf = (float *)s_cw_raw;
     const int nwt = Cout * 9 * C;
-    for (int i = threadIdx.x * 8; i < nwt; i += 256 * 8) *(f16x8 *)(s_cw + i) = *(const f16x8 *)(w + i);
+    if (WF32) {
+        for (int i = threadIdx.x * 8; i < nwt; i += 256 * 8) {
+            const f16x8 v = *(const f16x8 *)(w + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_cf[i + j] = (float)v[j];
+        }
+    } else {
+        for (int i = threadIdx.x * 8; i < nwt; i += 256 * 8) *(f16x8 *)(s_cw + i) = *(const f16x8 *)(w + i);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int c8n = C / 8, nitems = 9 * c8n;
@@ -638,27 +672,52 @@ __global__ __launch_bounds__(256) void k_conv_out(const f16 *__restrict__ x, con
         const int i = min(lane + 64 * u, nitems - 1);
         itap[u] = i / c8n; ic[u] = (i - itap[u] * c8n) * 8;
     }
-    for (int64_t pix = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; pix < npix; pix += ((int64_t)gridDim.x * 256) >> 6) {
-        const int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
+    // a wave walks its pixels with the NEXT pixel's loads issued before the current one is reduced (the kernel is bound by the
+    // latency of those loads, not by the arithmetic: one pixel in flight per wave took 41 us at 96^2 x 320 channels)
+    const int64_t pstep = ((int64_t)gridDim.x * 256) >> 6;
+    f16x8 xn[NU];
+    auto fetch = [&](int64_t pp_) {
+        const int64_t q = pp_ < npix ? pp_ : npix - 1;
+        const int b = (int)(q / (H * W)), p = (int)(q % (H * W));
         const int oy = p / W, ox = p % W;
-        f16x8 xv[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int iy = oy + itap[u] / 3 - 1, ix = ox + itap[u] % 3 - 1;
             const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-            xv[u] = *(const f16x8 *)(x + (((size_t)b * H + cy) * W + cx) * C + ic[u]);
-            if (lane + 64 * u >= nitems || iy != cy || ix != cx) xv[u] = zero8;
+            xn[u] = *(const f16x8 *)(x + (((size_t)b * H + cy) * W + cx) * C + ic[u]);
+            if (lane + 64 * u >= nitems || iy != cy || ix != cx) xn[u] = zero8;
         }
+    };
+    int64_t pix = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (pix < npix) fetch(pix);
+    for (; pix < npix; pix += pstep) {
+        const int b = (int)(pix / (H * W)), p = (int)(pix % (H * W));
+        const int oy = p / W, ox = p % W;
+        f16x8 xv[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) xv[u] = xn[u];
+        if (pix + pstep < npix) fetch(pix + pstep);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const f16 *wr = s_cw + itap[u] * C + ic[u];
+            float xf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = (float)xv[u][j];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 if (o < Cout) {
-                    f16x8 wv = *(const f16x8 *)(wr + o * 9 * C);
+                    if (WF32) {
+                        const float *wr = s_cf + itap[u] * C + ic[u] + o * 9 * C;
+                        const f32x4 w0 = *(const f32x4 *)wr, w1 = *(const f32x4 *)(wr + 4);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[o] += (float)xv[u][j] * (float)wv[j];
+                        for (int j = 0; j < 4; ++j) { acc[o] += xf[j] * w0[j]; }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { acc[o] += xf[4 + j] * w1[j]; }
+                    } else {
+                        const f16x8 wv = *(const f16x8 *)(s_cw + itap[u] * C + ic[u] + o * 9 * C);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[o] += xf[j] * (float)wv[j];
+                    }
                 }
             }
         }
@@ -674,16 +733,21 @@ __global__ __launch_bounds__(256) void k_conv_out(const f16 *__restrict__ x, con
 int ctx_conv_out_f16(const f16 *x, const f16 *w, const f16 *bias, int B, int H, int W, int C, int Cout, float *out, hipStream_t s)
 {
     int64_t nb = cdiv64((int64_t)B * H * W, 4);
-    if (nb > 512) nb = 512;                                   // every block stages the weights: keep them few and persistent
+    if (nb > 2048) nb = 2048;                                 // every block stages the weights: keep them few and persistent
     const int nitems = 9 * (C / 8);
-    const size_t lds = (size_t)Cout * 9 * C * sizeof(f16);
-    if (Cout > 4 || C % 8 != 0 || nitems > 64 * 12 || lds > 64 * 1024) {
+    const size_t lds16 = (size_t)Cout * 9 * C * sizeof(f16);
+    if (Cout > 4 || C % 8 != 0 || nitems > 64 * 12 || lds16 > 64 * 1024) {
         ctx_set_error("conv_out: unsupported C=%d Cout=%d", C, Cout);
         return CTX_E_ARG;
     }
-    if (nitems <= 64 * 3) hipLaunchKernelGGL(k_conv_out<3>, dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, B, H, W, C, Cout, out);
-    else if (nitems <= 64 * 6) hipLaunchKernelGGL(k_conv_out<6>, dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, B, H, W, C, Cout, out);
-    else hipLaunchKernelGGL(k_conv_out<12>, dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, B, H, W, C, Cout, out);
+    const bool f32w = 2 * lds16 <= 64 * 1024;
+    const size_t lds = f32w ? 2 * lds16 : lds16;
+#define CO_GO(NU_) do { if (f32w) hipLaunchKernelGGL((k_conv_out<NU_, true>), dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, B, H, W, C, Cout, out); \
+                        else hipLaunchKernelGGL((k_conv_out<NU_, false>), dim3((unsigned)nb), dim3(256), lds, s, x, w, bias, B, H, W, C, Cout, out); } while (0)
+    if (nitems <= 64 * 3) CO_GO(3);
+    else if (nitems <= 64 * 6) CO_GO(6);
+    else CO_GO(12);
+#undef CO_GO
     return CTX_OK;
 }
 
