@@ -283,15 +283,33 @@ def main():
 
     # measured sec/mesh (BASELINE metric, first half): one whole ConTEXTure.paint over this job's ranks, outside the timed region
     mesh_s, mesh_cover = None, None
+    mesh_hung = False
     if a.mesh:
-        try:
-            tr = make_painter(a, dev, unet)
-            mesh_s, mesh_cover = timed_paints(tr, 1, 1, dist, dev)
-            del tr
-        except Exception as e:                              # never lose the steps/s line to the mesh leg
-            mesh_s, mesh_cover = None, f"failed: {e}"
-            import traceback
-            traceback.print_exc()
+        # The leg runs in a worker thread under a deadline: an exception is reported in the line, and a rank that never comes back
+        # (a peer died before a collective) cannot take the steps/s line with it — rank 0 prints without the figure and every
+        # rank leaves through os._exit below.
+        import threading
+        box = {}
+
+        def _mesh_leg():
+            try:
+                torch.cuda.set_device(dev)
+                tr = make_painter(a, dev, unet)
+                box["res"] = timed_paints(tr, 1, 1, dist, dev)
+                del tr
+            except Exception as e:                          # never lose the steps/s line to the mesh leg
+                box["res"] = (None, f"failed: {e}")
+                import traceback
+                traceback.print_exc()
+
+        th = threading.Thread(target=_mesh_leg, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("CTX_BENCH_MESH_TIMEOUT_S", "180")))
+        if th.is_alive():
+            mesh_hung = True
+            mesh_s, mesh_cover = None, "timed out (a rank did not return from the mesh leg)"
+        else:
+            mesh_s, mesh_cover = box.get("res", (None, "failed: no result"))
 
     # HBM-side bytes per launch of the dominant kernel family: PMC counters cannot be collected from inside this process,
     # so the figure is the committed result of tools/pmc_traffic.sh (same command line, same workload) when present
@@ -331,7 +349,7 @@ def main():
                           "unit": "TFLOP/s", "launches_per_step": att_n, "kernel_ms_per_step": round(att_ms, 3)},
         }
         out["sec_per_mesh"] = round(mesh_s, 3) if mesh_s is not None else None
-        out["sec_per_mesh_note"] = (f"MEASURED: one ConTEXTure.paint of {a.mesh_path}, {a.mesh_views} views over {world} rank(s), "
+        out["sec_per_mesh_note"] = (f"{'MEASURED' if mesh_s is not None else 'NOT MEASURED (' + str(mesh_cover) + ')'}: one ConTEXTure.paint of {a.mesh_path}, {a.mesh_views} views over {world} rank(s), "
                                     f"{a.in_flight} views in flight per rank, 1200^2 render, 51 UNet evals + VAE decode per view, "
                                     f"view weights, UV scatter, atlas merge; coverage {mesh_cover}")
         if two is not None:
@@ -345,6 +363,9 @@ def main():
             except Exception as e:                      # never lose the GPU line to a host-side failure
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
+    if mesh_hung:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)                                         # the worker thread is stuck in a collective: no clean teardown possible
     if dist is not None:
         dist.destroy_process_group()
 
