@@ -68,13 +68,18 @@ def prepare_vertices(verts, faces, proj, cam):
     return fv_cam, fv_img, fn
 
 
-def rasterize(H, W, face_z, face_xy, feat, multiplier=1000.0, eps=1e-8):
+def rasterize(H, W, face_z, face_xy, feat, multiplier=1000.0, eps=1e-8, brute=None):
+    """brute=True: the literal pixel-parallel loop over every face; False: the face-major walk of
+    bounding boxes (identical results, see geometry_ref.c); None: brute below 2^27 pixel-face pairs."""
     face_z, face_xy, feat = _f32(face_z), _f32(face_xy), _f32(feat)
     B, F, _ = face_z.shape
     C = feat.shape[-1]
     out = np.empty((B, H, W, C), np.float32)
     idx = np.empty((B, H, W), np.int64)
-    lib().orc_rasterize(H, W, _p(face_z), _p(face_xy), _p(feat), B, F, C,
+    if brute is None:
+        brute = B * H * W * F <= (1 << 27)
+    fn = lib().orc_rasterize if brute else lib().orc_rasterize_bbox
+    fn(H, W, _p(face_z), _p(face_xy), _p(feat), B, F, C,
                         ctypes.c_float(multiplier), ctypes.c_float(eps), _p(out), _p(idx))
     return out, idx
 

@@ -93,6 +93,71 @@ def test_prepare_and_raster_bit_exact(dev, meshes, name, B, H, W):
     assert (o_i >= 0).mean() > 0.02
 
 
+@pytest.mark.parametrize("name", ["front", "side"])
+def test_product_raster_chain_vs_reference_depth_fixtures(dev, meshes, golden, golden_meta, name):
+    """PINNED against kaolin's own output as the reference holds it (shapes/spot_depth_{front,side}.pt, stored by
+    tests/golden/make_golden.py): the PRODUCT chain Mesh.normalize_mesh -> Renderer.get_camera_from_multiple_view ->
+    kal prepare_vertices (HIP) -> rasterize_fused (HIP) at the reference's default 1200^2 grid -> Renderer.normalize_multiple_depth
+    (HIP) re-based to [0.5, 1] -> utils.get_nonzero_region_tuple.  Silhouette equal on every pixel of the crop, depth within 1e-4
+    (to rounding once the fixture's own min / max are fitted); and the 1200^2 face ids / depths equal the oracle's bit for bit."""
+    from contexture_nerf_amd import kal, utils
+    from contexture_nerf_amd.mesh import Mesh
+    from contexture_nerf_amd.render import Renderer
+    from test_oracle_golden import check_against_spot_fixture
+    meta = golden_meta['spot_depth_' + name]
+    ref = golden['spot_depth_' + name]
+    G = meta['grid']
+    mesh = Mesh(device=dev, arrays=(meshes['spot_triangulated_v'], meshes['spot_triangulated_f'],
+                                    meshes['spot_triangulated_vt'], meshes['spot_triangulated_ft']))
+    mesh = mesh.normalize_mesh(inplace=True, target_scale=meta['scale'], dy=meta['dy'])
+    R = Renderer(dev, dim=(G, G))
+    theta = torch.tensor([np.deg2rad(meta['theta_deg'])], dtype=torch.float32, device=dev)
+    phi = torch.tensor([np.deg2rad(meta['phi_deg'])], dtype=torch.float32, device=dev)
+    radius = torch.tensor([meta['radius']], dtype=torch.float32, device=dev)
+    cam = R.get_camera_from_multiple_view(theta, phi, radius, look_at_height=meta['dy'])
+    fvc, fvi, fn = kal.render.mesh.prepare_vertices(mesh.vertices[None], mesh.faces, R.camera_projection, camera_transform=cam)
+    uva = kal.ops.mesh.index_vertices_by_faces(mesh.vt[None].to(dev), mesh.ft.to(dev))
+    raw, uv, idx, normals = kal.render.mesh.rasterize_fused(G, G, fvc, fvi, uva, fn)
+    depth = R.normalize_multiple_depth(raw)                               # render.py:48-74 with min_val = 0
+    mask = idx > -1
+    depth = torch.where(mask[..., None], 0.5 * depth + 0.5, depth)         # the fixtures' min_val = 0.5 (render.py:64-67)
+    h0, w0, h1, w1 = utils.get_nonzero_region_tuple(mask[0].float())
+    assert (h1 - h0, w1 - w0) == ref.shape
+    check_against_spot_fixture(depth[0, h0:h1, w0:w1, 0].cpu().numpy(), ref)
+    # the same 1200^2 raster against the oracle on the product's own vertices and camera: bit for bit
+    o_cam, o_img, o_fn = og.prepare_vertices(mesh.vertices[None].cpu().numpy(), mesh.faces.cpu().numpy(),
+                                             R.camera_projection.cpu().numpy(), cam.cpu().numpy())
+    assert np.array_equal(fvc.cpu().numpy(), o_cam) and np.array_equal(fvi.cpu().numpy(), o_img)
+    o_d, o_i = og.rasterize(G, G, o_cam[..., 2], o_img, o_cam[..., 2:3])
+    o_uv, _ = og.rasterize(G, G, o_cam[..., 2], o_img, uva.cpu().numpy())
+    assert np.array_equal(idx.cpu().numpy(), o_i), f"{(idx.cpu().numpy() != o_i).sum()} face ids differ at 1200^2"
+    assert np.array_equal(raw.cpu().numpy(), o_d) and np.array_equal(uv.cpu().numpy(), o_uv)
+    assert np.array_equal(normals.cpu().numpy(), og.gather_normals(o_i, o_fn))
+    assert np.array_equal(R.normalize_multiple_depth(raw).cpu().numpy(), og.normalize_multiple_depth(o_d))
+
+
+@pytest.mark.parametrize("name,B", [("nascar", 7), ("blub_no_texture", 1)])
+def test_raster_default_grid_bit_exact(dev, meshes, name, B):
+    """The reference's default render grid (1200^2, src/configs/train_config.py:11) with all 7 Zero123++ views: the size at
+    which k_raster_bin splits a tile's face scan into ranges.  Oracle = the face-major walk (== brute force, CPU test)."""
+    from contexture_nerf_amd import kal
+    verts, f, cam, proj = _scene(meshes, name, B)
+    o_cam, o_img, o_fn = og.prepare_vertices(verts, f, proj, cam)
+    g_cam, g_img, g_fn = kal.render.mesh.prepare_vertices(torch.tensor(verts, device=dev), torch.tensor(f, device=dev),
+                                                          torch.tensor(proj), camera_transform=torch.tensor(cam, device=dev))
+    uva = _uv_attr(meshes, name, f.shape[0])
+    H = W = 1200
+    o_d, o_i = og.rasterize(H, W, o_cam[..., 2], o_img, o_cam[..., 2:3])
+    o_uv, _ = og.rasterize(H, W, o_cam[..., 2], o_img, np.repeat(uva, B, 0))
+    f_d, f_uv, f_i, f_n = kal.render.mesh.rasterize_fused(H, W, g_cam, g_img, torch.tensor(uva, device=dev), g_fn)
+    assert np.array_equal(f_i.cpu().numpy(), o_i), f"{(f_i.cpu().numpy() != o_i).sum()} face ids differ"
+    assert np.array_equal(f_d.cpu().numpy(), o_d)
+    assert np.array_equal(f_uv.cpu().numpy(), o_uv)
+    assert np.array_equal(f_n.cpu().numpy(), og.gather_normals(o_i, o_fn))
+    g_d, g_i = kal.render.mesh.rasterize(H, W, g_cam[..., 2], g_img, g_cam[..., 2:3])
+    assert np.array_equal(g_i.cpu().numpy(), o_i) and np.array_equal(g_d.cpu().numpy(), o_d)
+
+
 def test_raster_edge_cases(dev):
     """Degenerate (zero-area) faces, exact depth ties (lowest index must win), faces off-screen, 1x1 image."""
     from contexture_nerf_amd import kal

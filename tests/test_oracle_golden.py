@@ -123,3 +123,93 @@ def test_raw2outputs_against_torch_formula():
     np.testing.assert_allclose(o[0], rgb.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(o[3], w.numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(o[4], (w * z).sum(-1).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_bbox_raster_equals_brute_force(meshes):
+    """oracle/geometry_ref.c: the face-major bounding-box walk must give the brute-force loop's results bit for bit
+    (ids, weights -> interpolated features), incl. ties, a degenerate face and faces off-screen."""
+    proj = og.generate_perspective_projection(np.pi / 3)
+    for name in ['spot_triangulated', 'nascar', 'sphere']:
+        v = og.normalize_mesh(meshes[name + '_v'], 0.6, 0.25)
+        f = meshes[name + '_f'].astype(np.int64)
+        cam = og.get_camera_from_multiple_view(np.float32([1.0471976, 1.9198622]), np.float32([0.3, 2.0943952]),
+                                               np.float32([1.5, 0.9]), 0.25)       # second view: faces leave the frame
+        fc, fi, _ = og.prepare_vertices(np.repeat(v[None], 2, 0), f, proj, cam)
+        a = og.rasterize(61, 83, fc[..., 2], fi, fc, brute=True)
+        b = og.rasterize(61, 83, fc[..., 2], fi, fc, brute=False)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    fxy = np.float32([[[-0.5, -0.5], [0.5, -0.5], [0.0, 0.5]], [[-0.5, -0.5], [0.5, -0.5], [0.0, 0.5]],
+                      [[0.2, 0.2], [0.2, 0.2], [0.2, 0.2]], [[3.0, 3.0], [4.0, 3.0], [3.5, 4.0]],
+                      [[-0.9, 0.1], [-0.1, 0.1], [-0.5, 0.9]]])[None]
+    fz = np.float32([[-2, -2, -2], [-2, -2, -2], [-1, -1, -1], [-1, -1, -1], [-1.5, -1.2, -1.7]])[None]
+    feat = np.random.default_rng(0).random((1, 5, 3, 3), dtype=np.float32)
+    for (H, W) in [(33, 47), (1, 1), (8, 300)]:
+        a = og.rasterize(H, W, fz, fxy, feat, brute=True)
+        b = og.rasterize(H, W, fz, fxy, feat, brute=False)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+        assert (a[1] == 1).sum() == 0 and (a[1] == 0).sum() > 0 or H == 1        # tie: the lower face id wins
+
+
+def spot_depth_chain(raster, meshes, meta):
+    """The chain the reference's depth fixtures went through (kaolin's own output, shapes/spot_depth_{front,side}.pt):
+    camera -> prepare_vertices -> rasterize @1200^2 -> normalise to [0.5, 1] (the min_val = 0.5 form the comment at
+    src/models/render.py:64-67 describes) -> crop by utils.get_nonzero_region_tuple (src/utils.py:92-113).
+    `raster(verts[1,V,3], faces, cam[1,4,3], proj, H, W) -> (depth[H,W] f32, face_idx[H,W] i64)`."""
+    v = og.normalize_mesh(meshes[meta['mesh'] + '_v'], meta['scale'], meta['dy'])
+    f = meshes[meta['mesh'] + '_f'].astype(np.int64)
+    cam = og.get_camera_from_multiple_view(np.float32([np.deg2rad(meta['theta_deg'])]), np.float32([np.deg2rad(meta['phi_deg'])]),
+                                           np.float32([meta['radius']]), meta['dy'])
+    proj = og.generate_perspective_projection(np.pi / 3)
+    G = meta['grid']
+    d, idx = raster(v[None], f, cam, proj, G, G)
+    mask = idx >= 0
+    mn, mx = d[mask].min(), d[mask].max()
+    nd = np.where(mask, np.float32(1 - meta['min_val']) * (d - mn) / (mx - mn) + np.float32(meta['min_val']), d).astype(np.float32)
+    return nd, idx
+
+
+def crop_box(mask):
+    """src/utils.py:92-113 restated on numpy (the product's utils.get_nonzero_region_tuple is checked against the
+    reference's own boxes in test_host_cpu.py)."""
+    nz = np.argwhere(mask)
+    a, c = nz[:, 0].min(), nz[:, 0].max()
+    b, e = nz[:, 1].min(), nz[:, 1].max()
+    size = max(c - a + 1, e - b + 1) * 1.1
+    hs = a - (size - (c - a + 1)) / 2
+    ws = b - (size - (e - b + 1)) / 2
+    h0, w0 = max(0, int(hs)), max(0, int(ws))
+    return h0, w0, min(mask.shape[0], int(h0 + size)), min(mask.shape[1], int(w0 + size))
+
+
+def check_against_spot_fixture(crop, ref):
+    """Silhouette bit for bit; depth within 1e-4 as is; and — because the fixture was normalised by ITS OWN min / max, which
+    sit on sliver triangles where the barycentric solve is ill-conditioned — to rounding once that affine map is removed."""
+    assert crop.shape == ref.shape
+    assert np.array_equal(crop > 0, ref > 0), f"{((crop > 0) != (ref > 0)).sum()} silhouette pixels differ"
+    fg = ref > 0
+    assert fg.sum() > 200000
+    assert np.abs(crop - ref).max() <= 1e-4
+    o, r = crop[fg].astype(np.float64), ref[fg].astype(np.float64)
+    A = np.stack([np.ones_like(o), o], 1)
+    coef = np.linalg.lstsq(A, r, rcond=None)[0]
+    resid = np.abs(r - A @ coef)
+    assert abs(coef[1] - 1) < 2e-5 and abs(coef[0]) < 2e-5
+    assert np.median(resid) <= 1.5e-7, np.median(resid)            # ~1 ulp of [0.5, 1]
+    assert np.percentile(resid, 99) <= 1.5e-6
+    return coef, resid
+
+
+def test_oracle_raster_chain_vs_reference_depth_fixtures(golden, golden_meta, meshes):
+    """PINS the raster chain (a1-a5, a26) to kaolin's own output as the reference holds it: at theta 60 / phi 180 (front) and
+    phi 90 (side) the oracle reproduces both silhouettes on every pixel of the 784^2 / 817^2 crops."""
+    def raster(verts, f, cam, proj, H, W):
+        fc, fi, _ = og.prepare_vertices(verts, f, proj, cam)
+        d, idx = og.rasterize(H, W, fc[..., 2], fi, fc[..., 2:3])
+        return d[0, ..., 0], idx[0]
+    for name in ['front', 'side']:
+        meta = golden_meta['spot_depth_' + name]
+        ref = golden['spot_depth_' + name]
+        nd, idx = spot_depth_chain(raster, meshes, meta)
+        h0, w0, h1, w1 = crop_box(idx >= 0)
+        assert (h1 - h0, w1 - w0) == tuple(meta['shape'][2:]) == ref.shape
+        check_against_spot_fixture(nd[h0:h1, w0:w1], ref)
