@@ -363,11 +363,33 @@ def main():
             except Exception as e:                      # never lose the GPU line to a host-side failure
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if mesh_hung:
+    # A rank whose mesh leg never came back sits in a collective (a GPU / RCCL hang): that is a FAILURE of the run, not a clean
+    # one.  The steps/s line above is already out; every rank now learns through the rendezvous store (not through the process
+    # group, whose queue the stuck collective blocks) whether ANY rank timed out, and if so all of them skip the teardown
+    # (destroy_process_group against a dead peer has no deadline) and leave non-zero.
+    if a.mesh and _any_rank_hung(dist, rank, world, mesh_hung):
+        print(f"[bench] rank {rank}: mesh leg timed out on {'this rank' if mesh_hung else 'a peer'}; exiting 3", file=sys.stderr)
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)                                         # the worker thread is stuck in a collective: no clean teardown possible
+        os._exit(3)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _any_rank_hung(dist, rank, world, mine, timeout_s=30.0):
+    """Uniform decision across ranks over the TCP rendezvous store; a store failure (rank 0 already gone) counts as hung."""
+    if dist is None or world == 1:
+        return mine
+    try:
+        import datetime
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = _get_default_store()
+        store.set(f"ctx_mesh_leg_{rank}", "hung" if mine else "ok")
+        keys = [f"ctx_mesh_leg_{r}" for r in range(world)]
+        store.wait(keys, datetime.timedelta(seconds=timeout_s))
+        return any(store.get(k) == b"hung" for k in keys)
+    except Exception as e:
+        print(f"[bench] rank {rank}: status exchange failed ({e})", file=sys.stderr)
+        return True
 
 
 if __name__ == "__main__":

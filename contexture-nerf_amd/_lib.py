@@ -29,7 +29,11 @@ SIGNATURES = {
     "ctx_texmap_bwd_plan_bytes": (_i64, [_i32, _i32, _i32]),
     "ctx_texmap_bwd_plan": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ctx_texture_mapping_bwd_binned_ws_bytes": (_i64, [_i32, _i32]),
-    "ctx_texture_mapping_bwd_binned": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ctx_texture_mapping_bwd_binned": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ctx_texmap_plan_max_res": (_i32, []),
+    "ctx_texmap_plan_stale": (_i32, [_vp, _vp]),
+    "ctx_uv_scatter_fixed": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "ctx_fixed_to_float": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "ctx_texture_pack4": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "ctx_texture_mapping_packed_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ctx_view_weights_max": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),

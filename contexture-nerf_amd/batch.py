@@ -7,7 +7,7 @@ mesh m+1 start on the ranks mesh m leaves idle and every rank ends up with the s
 Exchange steps, both over RCCL, one of each per mesh:
   phase A  all-reduce(MAX) of the per-face view-weight maxima [F]    (before painting: the masks gate the scatter)
   phase B  each rank paints its items, `views_in_flight` denoise loops at a time (items of different meshes may share a group)
-  phase C  all-reduce(SUM) of the atlas contribution [3+1, T, T]
+  phase C  all-reduce(SUM) of the atlas contribution [3+1, T, T] as int64 fixed-point sums (bit-identical for any world size)
 Every rank calls the collectives of every mesh in mesh order, whether or not it holds views of that mesh."""
 import torch
 from . import dist as D
@@ -45,7 +45,7 @@ class MeshBatchPainter:
                 slot[(m, vid)] = j
         # phase B: denoise loops, `views_in_flight` at a time across mesh boundaries
         T = self.trainers[0].cfg.guide.texture_resolution
-        contrib = [torch.zeros(4, T, T, device=self.device) for _ in self.trainers]
+        contrib = [torch.zeros(4, T, T, dtype=torch.int64, device=self.device) for _ in self.trainers]   # 2^-32 fixed point
         diffusion = self.trainers[0].diffusion
         infl = max(1, int(getattr(self.trainers[0].cfg.optim, 'views_in_flight', 3)))
         if not hasattr(diffusion, 'img2img_step_multi'):
@@ -65,7 +65,7 @@ class MeshBatchPainter:
                 tr = self.trainers[m]
                 rgb_output, obj_mask = tr._paint_finish(ctx, rgb)
                 k = slot[(m, self.view_ids[v])]
-                contrib[m] += tr.project_back_scatter(ctx['render_cache'], rgb_output, tr.view_weights[k:k + 1] & (obj_mask > 0))
+                tr.project_back_scatter(ctx['render_cache'], rgb_output, tr.view_weights[k:k + 1] & (obj_mask > 0), acc=contrib[m])
         # phase C: one all-reduce(SUM) per mesh
         res = []
         for m, tr in enumerate(self.trainers):

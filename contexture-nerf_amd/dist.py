@@ -40,8 +40,14 @@ def all_reduce_sum_(t, group=None):
     return t
 
 
-def merge_atlas(contrib, group=None, eps=1e-8):
-    """contrib [C+1,T,T] = per-rank weighted colour sums + weight sum -> atlas [C,T,T], coverage [T,T]."""
+def merge_atlas(contrib, group=None, eps=1e-8, frac_bits=32):
+    """contrib [C+1,T,T] = per-rank weighted colour sums + weight sum -> atlas [C,T,T], coverage [T,T].
+    int64 contrib (units of 2^-frac_bits, what `ConTEXTure.project_back_scatter` accumulates): the ranks' shards are summed as
+    INTEGERS and converted once, so the result does not depend on how the views were dealt over ranks — the N-rank atlas is
+    bit-identical to the 1-rank atlas.  A float32 contrib is summed as floats (order-dependent in the last bit)."""
     all_reduce_sum_(contrib, group)
+    if contrib.dtype == torch.int64:
+        # int64 -> double (round to nearest) -> exact power-of-two scale -> float32: the same three steps as ctx_fixed_to_float
+        contrib = (contrib.to(torch.float64) * (2.0 ** -frac_bits)).to(torch.float32)
     w = contrib[-1:]
     return contrib[:-1] / w.clamp_min(eps), w[0]

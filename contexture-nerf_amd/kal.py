@@ -107,37 +107,97 @@ def rasterize_fused(height, width, face_vertices_camera, face_vertices_image, uv
     return depth, uv, idx, normals
 
 
-_PLANS = {}          # (uv ptr, uv version, mask ptr, shape, T) -> (plan buffer, uv, mask): binning of a raster, reused across backwards
+# ---- UV scatter: plans ------------------------------------------------------------------------------
+# A plan (binning of a raster by atlas tile, uvscatter.hip) depends on (uv, mask) only.  Plans are cached ONLY when the caller
+# says the raster will come back (`reuse=True`: the SDS loop's render_cache); one-shot scatters build theirs and drop it.  The
+# cache is keyed by the tensors' addresses and versions, holds the tensors alive, is capped in bytes, and every scatter re-checks
+# a sampled checksum of (uv, mask) on the device: a raster rewritten behind the key poisons the result with NaN instead of
+# silently scattering along the old lists.
+_PLANS = {}
+PLAN_CACHE_BYTES = 768 << 20
 
 
-def scatter_add_texture(go, uv, mask_idx, grad_tex, binned=None):
-    """grad_tex [C,T,T] += bilinear scatter of go [B,H,W,C] (or [B,HW,C]) at uv — the backward of texture_mapping and the UV
-    back-projection scatter.  Large rasters (>= 64k pixels, C <= 4) go through the binned, atomics-free path of uvscatter.hip:
-    its plan depends on (uv, mask) only and is kept for the next call on the same raster (the SDS loop's render_cache)."""
+def clear_scatter_plans():
+    """Drop every cached scatter plan (and the rasters they keep alive)."""
+    _PLANS.clear()
+
+
+def _plan_bytes(ent):
+    return sum(t.numel() * t.element_size() for t in ent if t is not None)
+
+
+def binned_fits(C, T):
+    """True when the tile-binned scatter can take this atlas: C <= 4 and T within the plan's LDS histogram (2272)."""
+    return C <= 4 and T <= L.load().ctx_texmap_plan_max_res()
+
+
+def scatter_plan(uv, mask_idx, T, reuse=False):
+    """-> plan buffer for (uv [B,..,2] f32 contiguous, mask_idx | None, T)."""
+    lib = L.load()
+    B = uv.shape[0]
+    HW = uv[0].numel() // 2
+    key = (uv.data_ptr(), uv._version, None if mask_idx is None else (mask_idx.data_ptr(), mask_idx._version), B, HW, T)
+    ent = _PLANS.get(key) if reuse else None
+    if ent is not None:
+        return ent[0]
+    nbytes = lib.ctx_texmap_bwd_plan_bytes(B, HW, T)
+    if nbytes < 0:
+        raise L.CtxError(f"scatter_plan: B*HW = {B * HW} pixels do not fit the binned path")
+    plan = torch.empty(nbytes, dtype=torch.uint8, device=uv.device)
+    L.check(lib.ctx_texmap_bwd_plan(L.ptr(uv, torch.float32, "uv"), L.ptr(mask_idx), B, HW, T, L.ptr(plan), L.stream()))
+    if reuse:
+        ent = (plan, uv, mask_idx)                    # keep uv / mask alive: the key is their address
+        if _plan_bytes(ent) <= PLAN_CACHE_BYTES:
+            while _PLANS and sum(_plan_bytes(e) for e in _PLANS.values()) + _plan_bytes(ent) > PLAN_CACHE_BYTES:
+                _PLANS.pop(next(iter(_PLANS)))
+            _PLANS[key] = ent
+    return plan
+
+
+def scatter_add_texture(go, uv, mask_idx, grad_tex, binned=None, reuse=False):
+    """grad_tex [C,T,T] += bilinear scatter of go [B,H,W,C] (or [B,HW,C]) at uv — the backward of texture_mapping.  Large rasters
+    (>= 64k pixels, C <= 4, T within the plan's limit) go through the binned, atomics-free path of uvscatter.hip, whose fixed-point
+    unit follows max|go| of the call; otherwise the float-atomics kernel.  reuse: keep the plan for the next call on this raster."""
     lib = L.load()
     B = uv.shape[0]
     HW = uv[0].numel() // 2
     C, T = grad_tex.shape[0], grad_tex.shape[-1]
-    use = (B * HW >= 65536 and C <= 4) if binned is None else binned
+    use = (B * HW >= 65536 and binned_fits(C, T)) if binned is None else binned
     if not use:
         L.check(lib.ctx_texture_mapping_bwd(L.ptr(go, torch.float32, "grad_out"), L.ptr(uv, torch.float32, "uv"), B, HW, C, T,
                                             L.ptr(mask_idx), L.ptr(grad_tex, torch.float32, "grad_tex"), L.stream()))
         return grad_tex
-    key = (uv.data_ptr(), uv._version, None if mask_idx is None else (mask_idx.data_ptr(), mask_idx._version), B, HW, T)
-    ent = _PLANS.get(key)
-    if ent is None:
-        nbytes = lib.ctx_texmap_bwd_plan_bytes(B, HW, T)
-        if nbytes < 0:
-            raise L.CtxError(f"scatter_add_texture: B*HW = {B * HW} pixels do not fit the binned path")
-        plan = torch.empty(nbytes, dtype=torch.uint8, device=uv.device)
-        L.check(lib.ctx_texmap_bwd_plan(L.ptr(uv, torch.float32, "uv"), L.ptr(mask_idx), B, HW, T, L.ptr(plan), L.stream()))
-        while len(_PLANS) >= 4:
-            _PLANS.pop(next(iter(_PLANS)))
-        ent = _PLANS[key] = (plan, uv, mask_idx)      # keep uv / mask alive: the key is their address
+    plan = scatter_plan(uv, mask_idx, T, reuse=reuse)
     ws = torch.empty(lib.ctx_texture_mapping_bwd_binned_ws_bytes(C, T), dtype=torch.uint8, device=uv.device)
-    L.check(lib.ctx_texture_mapping_bwd_binned(L.ptr(go, torch.float32, "grad_out"), L.ptr(uv, torch.float32, "uv"), B, HW, C, T, L.ptr(ent[0]),
-                                               L.ptr(ws), L.ptr(grad_tex, torch.float32, "grad_tex"), L.stream()))
+    L.check(lib.ctx_texture_mapping_bwd_binned(L.ptr(go, torch.float32, "grad_out"), L.ptr(uv, torch.float32, "uv"), L.ptr(mask_idx), B, HW, C, T,
+                                               L.ptr(plan), L.ptr(ws), L.ptr(grad_tex, torch.float32, "grad_tex"), L.stream()))
     return grad_tex
+
+
+SCATTER_FRAC_BITS = 32          # unit of the painted-view accumulators: 2^-32 (values are colours x weights in [0, 1])
+
+
+def scatter_fixed(values, uv, mask_idx, acc, frac_bits=SCATTER_FRAC_BITS, reuse=False):
+    """acc [C,T,T] int64 += round(values * bilinear weight * 2^frac_bits): the UV back-projection of painted views as integer
+    sums (order-free, so view shards on different ranks add up to the same bits).  Any raster size; atlases beyond the plan's
+    limit (or C > 4) take the plan-less kernel (one int64 atomic per tap)."""
+    lib = L.load()
+    B = uv.shape[0]
+    HW = uv[0].numel() // 2
+    C, T = acc.shape[0], acc.shape[-1]
+    plan = scatter_plan(uv, mask_idx, T, reuse=reuse) if binned_fits(C, T) else None
+    L.check(lib.ctx_uv_scatter_fixed(L.ptr(values, torch.float32, "values"), L.ptr(uv, torch.float32, "uv"), L.ptr(mask_idx), B, HW, C, T,
+                                     L.ptr(plan), int(frac_bits), L.ptr(acc, torch.int64, "acc"), L.stream()))
+    return acc
+
+
+def fixed_to_float(acc, frac_bits=SCATTER_FRAC_BITS, out=None):
+    """int64 sums in units of 2^-frac_bits -> float32 (one rounding per texel)."""
+    lib = L.load()
+    if out is None:
+        out = torch.empty(acc.shape, dtype=torch.float32, device=acc.device)
+    L.check(lib.ctx_fixed_to_float(L.ptr(acc, torch.int64, "acc"), acc.numel(), int(frac_bits), 0, L.ptr(out, torch.float32, "out"), L.stream()))
+    return out
 
 
 class _TextureMapping(torch.autograd.Function):
@@ -182,7 +242,7 @@ class _TextureMapping(torch.autograd.Function):
         go = L.f32c(grad_out)
         if Bt_eff == 1:
             g = torch.zeros(Cc, T, T, device=go.device)
-            scatter_add_texture(go, uvc, mask_idx if has_mask else None, g)
+            scatter_add_texture(go, uvc, mask_idx if has_mask else None, g, reuse=True)
             if Bt > 1:      # input was an expand(): autograd sums the batch slices, so put the whole sum in slice 0
                 full = torch.zeros(tshape, device=go.device)
                 full[0] = g

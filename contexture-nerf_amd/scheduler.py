@@ -118,13 +118,17 @@ class DDPMScheduler:
     """diffusers 0.27.2 DDPMScheduler, the subset the reference's Zero123++ path uses: `add_noise` (src/training/trainer.py:746)
     and, because `init_zero123plus` swaps it in as the PIPELINE's scheduler (`DDPMScheduler.from_config(pipeline.scheduler.config)`,
     trainer.py:306), `set_timesteps(timesteps=[t])`, the identity `scale_model_input`, `init_noise_sigma == 1` and the ancestral
-    `step` (variance_type "fixed_small", no sample clipping) for epsilon / v prediction.  Host-side tensor arithmetic.
+    `step` (variance_type "fixed_small") for epsilon / v prediction.  `clip_sample` / `clip_sample_range` default to True / 1.0:
+    the EulerAncestral config the reference builds this scheduler from carries no `clip_sample` key, so `from_config` yields the
+    DDPM defaults and `pred_original_sample` is clamped to [-1, 1] before `prev_sample` is formed (the SDS loop only reads
+    `noise_pred` through the callback and is unaffected; sampling through the pipeline is).  Host-side tensor arithmetic.
     PARITY UNPINNED vs diffusers (absent offline)."""
     order = 1
     init_noise_sigma = 1.0
 
     def __init__(self, beta_start=0.00085, beta_end=0.012, num_train_timesteps=1000, beta_schedule="scaled_linear",
-                 prediction_type="v_prediction", **kw):
+                 prediction_type="v_prediction", clip_sample=True, clip_sample_range=1.0, **kw):
+        self.clip_sample, self.clip_sample_range = bool(clip_sample), float(clip_sample_range)
         if beta_schedule == "scaled_linear":
             self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         elif beta_schedule == "linear":
@@ -175,6 +179,8 @@ class DDPMScheduler:
             x0 = a_t ** 0.5 * sample - b_t ** 0.5 * model_output
         else:
             raise ValueError(f"DDPMScheduler: prediction_type {self.prediction_type!r}")
+        if self.clip_sample:
+            x0 = x0.clamp(-self.clip_sample_range, self.clip_sample_range)
         prev = (a_prev ** 0.5 * cur_b / b_t) * x0 + (cur_a ** 0.5 * b_prev / b_t) * sample
         if t > 0:
             var = max(b_prev / b_t * cur_b, 1e-20)                                # fixed_small

@@ -138,25 +138,28 @@ class ConTEXTure:
         return self.paint_viewpoints_multi([data_a, data_b], image_size, num_inference_steps)
 
     # ---- north_star "UV back-projection" (absent in the reference) ----------------------------
-    def project_back_scatter(self, render_cache, rgb_output, weight_mask):
-        """Scatter a painted view into the atlas: contrib[0:3] += w*rgb, contrib[3] += w at the 4 bilinear texels of
-        each visible pixel (w = view weight mask).  Implemented with the texture-sampling backward kernel."""
+    def project_back_scatter(self, render_cache, rgb_output, weight_mask, acc=None):
+        """Scatter a painted view into the atlas: acc[0:3] += w*rgb, acc[3] += w at the 4 bilinear texels of each visible
+        pixel (w = view weight mask).  acc [4,T,T] is INT64 in units of 2^-32 (kal.SCATTER_FRAC_BITS; uvscatter.hip's fixed mode):
+        integer sums do not depend on the order of views, chunks or ranks, so the all-reduced atlas of N ranks equals the 1-rank
+        atlas bit for bit (dist.merge_atlas converts once, after the collective)."""
         from . import kal
         uv = render_cache['uv_features']
         face_idx = render_cache['face_idx']
         T = self.cfg.guide.texture_resolution
         w = weight_mask.to(torch.float32).permute(0, 2, 3, 1)
         go = torch.cat([rgb_output.permute(0, 2, 3, 1) * w, w], dim=-1).contiguous()
-        contrib = torch.zeros(4, T, T, device=uv.device)
+        if acc is None:
+            acc = torch.zeros(4, T, T, dtype=torch.int64, device=uv.device)
         uvc = uv if (uv.dtype == torch.float32 and uv.is_contiguous()) else L.f32c(uv)
-        kal.scatter_add_texture(go, uvc, face_idx.contiguous(), contrib)
-        return contrib
+        kal.scatter_fixed(go, uvc, face_idx.contiguous(), acc)
+        return acc
 
     @torch.no_grad()
     def project_back(self, render_cache, background, rgb_output, object_mask, update_mask, z_normals=None, z_normals_cache=None):
         """The call the reference makes at trainer.py:1076-1090 (its body is missing there; upstream TEXTure fits the
         texture image to `rgb_output` under `update_mask` by Adam): here the painted pixels are scattered straight into the
-        running atlas contribution `self.atlas_contrib` [3+1,T,T] with weight = update_mask * object_mask (* z_normals when given:
+        running atlas contribution `self.atlas_acc` [3+1,T,T] (int64 fixed point; `self.atlas_contrib` = its float image) with weight = update_mask * object_mask (* z_normals when given:
         the view-facing weight TEXTure's masks are built from; * the view-weight mask of this view when `define_view_weights` ran
         for it), then the view is re-rendered from the normalised atlas.  `z_normals_cache` is accepted for the call contract and
         not read (there is no meta-texture in this build).  -> fitted_pred_rgb [B,3,H,W].  PARITY UNPINNED (no reference body)."""
@@ -165,10 +168,10 @@ class ConTEXTure:
         w = (update_mask > 0).float() * (object_mask > 0).float()
         if z_normals is not None:
             w = w * z_normals.clamp(0, 1)
-        contrib = self.project_back_scatter(render_cache, rgb_output, w)
-        if getattr(self, 'atlas_contrib', None) is None:
-            self.atlas_contrib = torch.zeros(4, T, T, device=self.device)
-        self.atlas_contrib += contrib
+        if getattr(self, 'atlas_acc', None) is None:
+            self.atlas_acc = torch.zeros(4, T, T, dtype=torch.int64, device=self.device)
+        self.project_back_scatter(render_cache, rgb_output, w, acc=self.atlas_acc)
+        self.atlas_contrib = kal.fixed_to_float(self.atlas_acc)
         wsum = self.atlas_contrib[3:]
         atlas = (self.atlas_contrib[:3] / wsum.clamp_min(1e-8))[None]
         uv, face_idx = render_cache['uv_features'], render_cache['face_idx']
@@ -337,7 +340,7 @@ class ConTEXTure:
         n = len(self.train_views)
         mine = D.shard_views(n, self.rank, self.world)
         T = self.cfg.guide.texture_resolution
-        contrib = torch.zeros(4, T, T, device=self.device)
+        contrib = torch.zeros(4, T, T, dtype=torch.int64, device=self.device)      # 2^-32 fixed point: see project_back_scatter
         masks = self.define_view_weights(mine)          # an idle rank (no views of this mesh) still joins the all-reduce(MAX)
         # a rank that owns several views keeps `views_in_flight` of them (default 3) in the denoise loop at once
         infl = max(1, int(getattr(self.cfg.optim, 'views_in_flight', 3)))
@@ -350,11 +353,11 @@ class ConTEXTure:
                 res = self.paint_viewpoints_multi([self.train_views[k] for k in grp], image_size=image_size,
                                                   num_inference_steps=num_inference_steps)
                 for o, (rgb, obj_mask, last) in enumerate(res):
-                    contrib += self.project_back_scatter(last['render_cache'], rgb, masks[j + o:j + o + 1] & (obj_mask > 0))
+                    self.project_back_scatter(last['render_cache'], rgb, masks[j + o:j + o + 1] & (obj_mask > 0), acc=contrib)
             else:
                 rgb, obj_mask = self.paint_viewpoint(self.train_views[grp[0]], should_project_back=False, image_size=image_size,
                                                      num_inference_steps=num_inference_steps)
-                contrib += self.project_back_scatter(self._last['render_cache'], rgb, masks[j:j + 1] & (obj_mask > 0))
+                self.project_back_scatter(self._last['render_cache'], rgb, masks[j:j + 1] & (obj_mask > 0), acc=contrib)
             j += len(grp)
         atlas, coverage = D.merge_atlas(contrib, self.group)
         self.atlas, self.atlas_coverage = atlas, coverage

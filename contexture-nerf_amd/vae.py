@@ -185,8 +185,14 @@ class AutoencoderKL:
         """[B,3,H,W] in [-1,1] (may require grad) -> moments [B,2L,H/8,W/8] with autograd to x: the seam `vae.encode(...)` has in
         the reference's SDS loop, where the loss is backpropagated THROUGH the frozen encoder into the rendered views
         (src/training/trainer.py:732, 866).  Forward = ctx_vae_encode_train (keeps the tape in this engine's workspace),
-        backward = ctx_vae_encode_bwd; one backward per forward, no other call on this engine in between."""
+        backward = ctx_vae_encode_bwd; one backward per forward, no other call on this engine in between.  A later training forward
+        supersedes a tape that never saw its backward (the stale backward then raises); `drop_tape()` releases it explicitly."""
         return _VaeEncodeFn.apply(self, x)
+
+    def drop_tape(self):
+        """Forget a training forward whose backward will not be run (no-grad calls go back to this engine, not to a sibling)."""
+        self._tape_pending = False
+        self._tape_gen = getattr(self, '_tape_gen', 0) + 1
 
     def encode(self, x):
         """x [B,3,H,W] in [-1,1] -> namespace(latent_dist=DiagonalGaussianDistribution-like with .sample() / .mode() / .mean / .logvar).
@@ -228,8 +234,10 @@ class _VaeEncodeFn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         if Cc != vae.config['out_channels']:
             raise L.CtxError(f"vae.encode: expected {vae.config['out_channels']} image channels, got {Cc}")
-        if vae._tape_pending:
-            raise L.CtxError("vae.encode: a training forward of this engine still waits for its backward (one tape per engine)")
+        # One tape per engine.  A NEW training forward supersedes a tape whose backward never came (its graph was dropped by an
+        # exception, or the call was an eval on a tensor that happened to require grad): the generation counter makes the stale
+        # context's backward fail loudly instead of differentiating through the wrong tape.
+        vae._tape_gen = getattr(vae, '_tape_gen', 0) + 1
         need = vae._lib.ctx_vae_encode_train_workspace_bytes(vae._h, B, H, W)
         if need < 0:
             f = 2 ** (len(vae.config['block_out_channels']) - 1)
@@ -241,17 +249,22 @@ class _VaeEncodeFn(torch.autograd.Function):
         f = 2 ** (len(vae.config['block_out_channels']) - 1)
         mom = torch.empty(B, 2 * vae.config['latent_channels'], H // f, W // f, device=vae.device)
         L.check(vae._lib.ctx_vae_encode_train(vae._h, L.ptr(x, torch.float32, "image"), B, H, W, L.ptr(mom), L.stream()))
-        ctx.vae, ctx.shape = vae, (B, Cc, H, W)
+        ctx.vae, ctx.shape, ctx.gen = vae, (B, Cc, H, W), vae._tape_gen
         vae._tape_pending = True
         return mom
 
     @staticmethod
     def backward(ctx, g):
         vae = ctx.vae
+        if ctx.gen != vae._tape_gen or not vae._tape_pending:
+            raise L.CtxError("vae.encode backward: this engine's tape was overwritten by a later training forward (or already "
+                             "consumed); one backward per forward, in order")
         vae._tape_pending = False
         g = L.f32c(g, vae.device)
         gmax = float(g.abs().max())
-        if not (gmax > 0.0) or gmax != gmax or gmax == float('inf'):
+        if gmax != gmax or gmax == float('inf'):               # NaN / Inf in the incoming gradient: propagate, as torch autograd would
+            return None, torch.full(ctx.shape, float('nan'), device=vae.device)
+        if not (gmax > 0.0):
             return None, torch.zeros(ctx.shape, device=vae.device)
         gscale = 2.0 ** round(__import__('math').log2(16.0 / gmax))          # fp16 gradients: max |g| scaled to ~16, a power of two
         dx = torch.empty(ctx.shape, device=vae.device)

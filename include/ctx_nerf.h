@@ -80,13 +80,28 @@ int32_t ctx_texture_mapping_bwd(const float *grad_out, const float *uv, int32_t 
                                 ctx_stream_t stream);
 /* The same scatter without global float atomics (uvscatter.hip): pixels are binned by 32 x 32-texel atlas tile once per raster
    (`plan`: depends on uv / mask_idx only, reusable by every backward of the SDS loop), then one workgroup per tile accumulates
-   its pixel list in LDS as 2^-32 fixed-point int64 sums and writes each texel once.  Bit-reproducible (integer sums do not depend
-   on arrival order); C <= 4, B*HW < 2^32.  grad_tex [C,T,T] is added to (as above).  ws: ctx_texture_mapping_bwd_binned_ws_bytes. */
+   its pixel list in LDS as fixed-point int64 sums and writes each texel once.  Bit-reproducible (integer sums do not depend
+   on arrival order); C <= 4, B*HW < 2^32, T <= ctx_texmap_plan_max_res().  grad_tex [C,T,T] is added to (as above).
+   The fixed-point unit is chosen per call from max|grad_out| (2^-E of the largest tap, E = 62 - ceil(log2(B*HW))), so gradients of
+   any magnitude keep the same relative resolution; a non-finite grad_out, or a (uv, mask_idx) that no longer matches the plan's
+   sampled checksum, turns the whole of grad_tex into NaN (and ctx_texmap_plan_stale() reports the latter).
+   ws: ctx_texture_mapping_bwd_binned_ws_bytes. */
 int64_t ctx_texmap_bwd_plan_bytes(int32_t B, int32_t HW, int32_t T);
+int32_t ctx_texmap_plan_max_res(void);
 int32_t ctx_texmap_bwd_plan(const float *uv, const int64_t *mask_idx, int32_t B, int32_t HW, int32_t T, void *plan, ctx_stream_t stream);
+int32_t ctx_texmap_plan_stale(const void *plan, ctx_stream_t stream);
 int64_t ctx_texture_mapping_bwd_binned_ws_bytes(int32_t C, int32_t T);
-int32_t ctx_texture_mapping_bwd_binned(const float *grad_out, const float *uv, int32_t B, int32_t HW, int32_t C, int32_t T,
+int32_t ctx_texture_mapping_bwd_binned(const float *grad_out, const float *uv, const int64_t *mask_idx, int32_t B, int32_t HW, int32_t C, int32_t T,
                                        const void *plan, void *ws, float *grad_tex, ctx_stream_t stream);
+
+/* UV back-projection of painted views (north_star "torch-scatter UV back-projection"; call contract src/training/trainer.py:1076-1090)
+   as INTEGER sums: acc [C,T,T] int64 += round(values * bilinear weight * 2^frac_bits) at the 4 texels of every unmasked pixel.
+   The caller owns acc across calls and ranks: view shards are all-reduced (SUM, int64) and converted once by ctx_fixed_to_float,
+   so the N-rank atlas equals the 1-rank atlas bit for bit.  Requires |values| * B*HW * 2^frac_bits < 2^63.
+   plan: as above, or NULL (any T, any C: one global int64 atomic per tap). */
+int32_t ctx_uv_scatter_fixed(const float *values, const float *uv, const int64_t *mask_idx, int32_t B, int32_t HW, int32_t C, int32_t T,
+                             const void *plan, int32_t frac_bits, int64_t *acc, ctx_stream_t stream);
+int32_t ctx_fixed_to_float(const int64_t *acc, int64_t n, int32_t frac_bits, int32_t accumulate, float *out, ctx_stream_t stream);
 
 /* Texel-interleaved forward for C <= 4 and one texture shared by the batch (the reference's texture_img.expand(B, ...),
    render.py:133-135): ctx_texture_pack4 repacks [C,T,T] into [T,T,4] once, ctx_texture_mapping_packed_fwd then gathers one

@@ -114,6 +114,19 @@ def texture_mapping_bwd(grad_out, uv, T):
     return g
 
 
+def uv_scatter_fixed(values, uv, mask_idx, T, frac_bits=32, acc=None):
+    """-> acc [C,T,T] int64 (+= when given): integer restatement of the UV back-projection scatter."""
+    values, uv = _f32(values), _f32(uv)
+    B = uv.shape[0]
+    HW = uv[0].size // 2
+    C = values.shape[-1]
+    if acc is None:
+        acc = np.zeros((C, T, T), np.int64)
+    mi = _i64(mask_idx) if mask_idx is not None else None
+    lib().orc_uv_scatter_fixed(_p(values), _p(uv), _p(mi) if mi is not None else None, B, HW, C, T, int(frac_bits), _p(acc))
+    return acc
+
+
 def gather_normals(face_idx, fnorm):
     face_idx, fnorm = _i64(face_idx), _f32(fnorm)
     B, F, _ = fnorm.shape

@@ -312,6 +312,33 @@ void orc_texture_mapping_bwd(const float *grad_out, const float *uv, int B, int 
     free(acc);
 }
 
+/* The same scatter as INTEGER sums (the product's ctx_uv_scatter_fixed; north_star "bit-exact for UV index / scatter"):
+   every tap g*w is one float product (as above), scaled exactly by 2^frac, rounded to nearest-even and added as int64.
+   Integer addition is order-free, so any traversal order gives these bits.  mask_idx (nullable): pixels with a negative
+   face index are skipped. */
+void orc_uv_scatter_fixed(const float *values, const float *uv, const int64_t *mask_idx, int B, int HW, int C, int T,
+                          int frac, int64_t *acc)
+{
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < HW; ++i) {
+            size_t pix = (size_t)b * HW + i;
+            if (mask_idx && mask_idx[pix] < 0) continue;
+            float u = uv[pix * 2 + 0], v = uv[pix * 2 + 1];
+            float ix = src_index(u * 2.0f - 1.0f, T), iy = src_index((1.0f - v) * 2.0f - 1.0f, T);
+            float fx = floorf(ix), fy = floorf(iy);
+            int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+            float w[4] = {((float)x1 - ix) * ((float)y1 - iy), (ix - (float)x0) * ((float)y1 - iy),
+                          ((float)x1 - ix) * (iy - (float)y0), (ix - (float)x0) * (iy - (float)y0)};
+            int xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
+            const float *g = values + pix * C;
+            for (int k = 0; k < 4; ++k) {
+                if (xs[k] < 0 || xs[k] >= T || ys[k] < 0 || ys[k] >= T) continue;
+                for (int c = 0; c < C; ++c)
+                    acc[((size_t)c * T + ys[k]) * T + xs[k]] += llrintf(ldexpf(g[c] * w[k], frac));
+            }
+        }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 void orc_gather_normals(const int64_t *face_idx, const float *fnorm, int B, int HW, int F, float *out)
 {

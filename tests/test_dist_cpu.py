@@ -38,18 +38,19 @@ def _worker(rank, world, port, tmp):
     seen = np.isfinite(full_max)
     assert np.array_equal(gmax[seen], full_max[seen])
     assert np.array_equal(masks, full_masks[mine])
-    # atlas: per-rank contributions (weights in channel 3) summed over ranks == single-process sum
+    # atlas: per-rank int64 fixed-point contributions (weights in channel 3) summed over ranks == the single-process sum, bit for bit
     T = 16
     contrib_all = rng.random((B, 4, T, T)).astype(np.float32)
     contrib_all[:, 3] = (contrib_all[:, 3] > 0.5)
-    local = torch.from_numpy(contrib_all[mine].sum(0))
+    fixed_all = np.rint(contrib_all.astype(np.float64) * 2.0 ** 32).astype(np.int64)
+    local = torch.from_numpy(fixed_all[mine].sum(0))
     atlas, cov = D.merge_atlas(local.clone())
-    want = contrib_all[0::1]
-    tot = np.zeros((4, T, T), np.float32)
-    for rk in range(world):                              # same association order as the collective: per-rank sums, then ranks
-        tot += contrib_all[[k for k in range(B) if k % world == rk]].sum(0)
-    np.testing.assert_allclose(cov.numpy(), tot[3], rtol=0, atol=0)
-    np.testing.assert_allclose(atlas.numpy(), tot[:3] / np.maximum(tot[3:], 1e-8), rtol=1e-6, atol=1e-6)
+    tot = (fixed_all.sum(0).astype(np.float64) * 2.0 ** -32).astype(np.float32)          # any order: integer sums
+    assert np.array_equal(cov.numpy(), tot[3])
+    assert np.array_equal(atlas.numpy(), tot[:3] / np.maximum(tot[3:], np.float32(1e-8)))
+    # a float32 contrib still goes through (summed as floats, per-rank sums then ranks)
+    atlas_f, cov_f = D.merge_atlas(torch.from_numpy(contrib_all[mine].sum(0)))
+    np.testing.assert_allclose(cov_f.numpy(), tot[3], rtol=0, atol=1e-5)
     # ray path (configs[4]): contiguous row tiles, ragged H, gathered image == the unsharded one
     from contexture_nerf_amd import volume_render as vr
     Hh = 13

@@ -3,8 +3,9 @@
 executed with the HIP kernel calls stubbed at the `_lib` seam: `_lib.load()` returns a numpy stand-in for the three entry points
 this path calls, `_lib.ptr()` hands the tensor through.  Nothing from oracle/ does the per-rank work here; the expected values
 are computed in plain numpy over ALL views in one process.  What is checked: sharding, the order and content of the collectives
-(all-reduce(MAX) of per-face maxima between the two view-weight phases, all-reduce(SUM) of the atlas contribution), that a rank
-without views still joins them, and that the result equals the unsharded one."""
+(all-reduce(MAX) of per-face maxima between the two view-weight phases, all-reduce(SUM) of the int64 fixed-point atlas
+contribution), that a rank
+without views still joins them, and that the result equals the unsharded one BIT FOR BIT (integer sums)."""
 import os
 import sys
 import types
@@ -36,12 +37,16 @@ class FakeLib:
             o[b] = np.where(f[b] >= 0, ~(z[b][fc] < m[fc]), True)
         return 0
 
-    def ctx_texture_mapping_bwd(self, go, uv, B, HW, C, T_, face_idx, contrib, stream):
+    def ctx_texmap_plan_max_res(self):
+        return 0                                           # no tile plans here: the scatter takes its plan-less form
+
+    def ctx_uv_scatter_fixed(self, go, uv, face_idx, B, HW, C, T_, plan, frac, acc, stream):
+        assert plan is None and acc.dtype == torch.int64
         g = go.numpy().reshape(B * HW, C); u = uv.numpy().reshape(B * HW, 2); f = face_idx.numpy().reshape(B * HW)
-        out = contrib.numpy()
+        out = acc.numpy()
         x = np.clip((u[:, 0] * T_).astype(np.int64), 0, T_ - 1); y = np.clip(((1 - u[:, 1]) * T_).astype(np.int64), 0, T_ - 1)
-        for i in np.nonzero(f >= 0)[0]:                    # nearest-texel stand-in for the bilinear scatter
-            out[:, y[i], x[i]] += g[i]
+        for i in np.nonzero(f >= 0)[0]:                    # nearest-texel stand-in for the bilinear scatter, integer sums
+            out[:, y[i], x[i]] += np.rint(g[i].astype(np.float64) * 2.0 ** frac).astype(np.int64)
         return 0
 
     def ctx_last_error(self):
@@ -117,7 +122,7 @@ def expected(n_views, key=0):
     for fi, fnz, _, _ in vs:
         for f in np.unique(fi[fi >= 0]):
             mx[f] = max(mx[f], fnz[f])
-    masks, contrib = [], np.zeros((4, T, T), np.float32)
+    masks, contrib = [], np.zeros((4, T, T), np.int64)
     for fi, fnz, uv, rgb in vs:
         fc = np.clip(fi, 0, None)
         m = np.where(fi >= 0, ~(fnz[fc] < mx[fc]), True)
@@ -125,9 +130,21 @@ def expected(n_views, key=0):
         w = (m & (fi >= 0)).astype(np.float32)
         x = np.clip((uv[..., 0] * T).astype(np.int64), 0, T - 1); y = np.clip(((1 - uv[..., 1]) * T).astype(np.int64), 0, T - 1)
         for i, j in zip(*np.nonzero(fi >= 0)):
-            contrib[:3, y[i, j], x[i, j]] += rgb[:, i, j] * w[i, j]
-            contrib[3, y[i, j], x[i, j]] += w[i, j]
-    return np.stack(masks), contrib
+            contrib[:3, y[i, j], x[i, j]] += _fix(rgb[:, i, j] * w[i, j])
+            contrib[3, y[i, j], x[i, j]] += _fix(w[i, j])
+    return np.stack(masks), _unfix(contrib)
+
+
+def _fix(v):
+    return np.rint(np.asarray(v, np.float32).astype(np.float64) * 2.0 ** 32).astype(np.int64)
+
+
+def _unfix(acc):
+    return (acc.astype(np.float64) * 2.0 ** -32).astype(np.float32)
+
+
+def _atlas(c):
+    return c[:3] / np.maximum(c[3:], np.float32(1e-8))
 
 
 def _worker(rank, world, port, tmp):
@@ -164,8 +181,9 @@ def _worker(rank, world, port, tmp):
     tr = make_trainer(rank, world, n)
     atlas, cov = tr.paint()
     assert calls == [('MAX', (F,)), ('SUM', (4, T, T))]
-    np.testing.assert_allclose(cov.numpy(), want_contrib[3], rtol=0, atol=1e-6)
-    np.testing.assert_allclose(atlas.numpy(), want_contrib[:3] / np.maximum(want_contrib[3:], 1e-8), rtol=1e-5, atol=1e-6)
+    # integer sums all-reduced as int64: the 2-rank atlas equals the single-process one BIT FOR BIT
+    assert np.array_equal(cov.numpy(), want_contrib[3])
+    assert np.array_equal(atlas.numpy(), _atlas(want_contrib))
     assert np.array_equal(tr.view_weights[:, 0].numpy(), want_masks[mine])
 
     # 3. one view, two ranks: rank 1 is idle and must still join both collectives
@@ -175,7 +193,7 @@ def _worker(rank, world, port, tmp):
     assert calls == [('MAX', (F,)), ('SUM', (4, T, T))]
     m1, c1 = expected(1)
     assert (tr1.view_weights is None) == (rank == 1)
-    np.testing.assert_allclose(cov1.numpy(), c1[3], rtol=0, atol=1e-6)
+    assert np.array_equal(cov1.numpy(), c1[3]) and np.array_equal(atlas1.numpy(), _atlas(c1))
 
     # 4. BASELINE configs[3] driver: 3 meshes x 3 views over 2 ranks; items of different meshes share a group in flight
     calls.clear()
@@ -195,15 +213,15 @@ def _worker(rank, world, port, tmp):
         for fi_, fnz_, _, _ in vs:
             for f in np.unique(fi_[fi_ >= 0]):
                 mx[f] = max(mx[f], fnz_[f])
-        c = np.zeros((4, T, T), np.float32)
+        c = np.zeros((4, T, T), np.int64)
         for fi_, fnz_, uv_, rgb_ in vs:
             fc = np.clip(fi_, 0, None)
             wgt = (np.where(fi_ >= 0, ~(fnz_[fc] < mx[fc]), True) & (fi_ >= 0)).astype(np.float32)
             x = np.clip((uv_[..., 0] * T).astype(np.int64), 0, T - 1); y = np.clip(((1 - uv_[..., 1]) * T).astype(np.int64), 0, T - 1)
             for i, j in zip(*np.nonzero(fi_ >= 0)):
-                c[:3, y[i, j], x[i, j]] += rgb_[:, i, j] * wgt[i, j]; c[3, y[i, j], x[i, j]] += wgt[i, j]
-        np.testing.assert_allclose(res[m][1].numpy(), c[3], rtol=0, atol=1e-6)
-        np.testing.assert_allclose(res[m][0].numpy(), c[:3] / np.maximum(c[3:], 1e-8), rtol=1e-5, atol=1e-6)
+                c[:3, y[i, j], x[i, j]] += _fix(rgb_[:, i, j] * wgt[i, j]); c[3, y[i, j], x[i, j]] += _fix(wgt[i, j])
+        c = _unfix(c)
+        assert np.array_equal(res[m][1].numpy(), c[3]) and np.array_equal(res[m][0].numpy(), _atlas(c))
     torch.save(torch.tensor(1), os.path.join(tmp, f"ok{rank}"))
     dist.destroy_process_group()
 

@@ -651,15 +651,76 @@ def test_project_back_scatter_vs_oracle(dev, meshes):
     tr = ConTEXTure.__new__(ConTEXTure)
     tr.cfg = type('C', (), {'guide': type('G', (), {'texture_resolution': T})()})()
     contrib = tr.project_back_scatter(dict(uv_features=uv, face_idx=face_idx), rgb, wmask)
-    assert contrib.shape == (4, T, T)
+    assert contrib.shape == (4, T, T) and contrib.dtype == torch.int64
     w = wmask.float().permute(0, 2, 3, 1)
     go = torch.cat([rgb.permute(0, 2, 3, 1) * w, w], -1).cpu().numpy()
-    go = go * (face_idx.cpu().numpy() >= 0)[..., None]                                # the kernel's face-index mask
-    want = og.texture_mapping_bwd(go, uv.cpu().numpy(), T)
-    want = want.sum(0) if want.ndim == 4 else want
-    scale = np.abs(want).max()
-    np.testing.assert_allclose(contrib.cpu().numpy(), want, rtol=0, atol=2e-5 * max(scale, 1.0))      # float atomics: order-dependent sums
-    assert float(contrib[3].sum()) > 1000
+    # BIT-EXACT against the integer oracle (2^-32 fixed point; integer sums are order-free)
+    want_i = og.uv_scatter_fixed(go, uv.cpu().numpy(), face_idx.cpu().numpy(), T, kal.SCATTER_FRAC_BITS)
+    assert np.array_equal(contrib.cpu().numpy(), want_i), f"{(contrib.cpu().numpy() != want_i).sum()} texel sums differ"
+    # a second view added into the same accumulator == the oracle fed both; conversions agree bit for bit
+    tr.project_back_scatter(dict(uv_features=uv[:1].contiguous(), face_idx=face_idx[:1].contiguous()), rgb[:1], wmask[:1], acc=contrib)
+    og.uv_scatter_fixed(go[:1], uv[:1].cpu().numpy(), face_idx[:1].cpu().numpy(), T, kal.SCATTER_FRAC_BITS, acc=want_i)
+    assert np.array_equal(contrib.cpu().numpy(), want_i)
+    as_float = kal.fixed_to_float(contrib)
+    assert np.array_equal(as_float.cpu().numpy(), (want_i.astype(np.float64) * 2.0 ** -32).astype(np.float32))
+    assert torch.equal(as_float, (contrib.to(torch.float64) * 2.0 ** -32).to(torch.float32))         # dist.merge_atlas' conversion
+    # and it is the float scatter the oracle's grid_sample backward describes
+    go2 = np.concatenate([go, go[:1]], 0) * (np.concatenate([face_idx.cpu().numpy(), face_idx[:1].cpu().numpy()], 0) >= 0)[..., None]
+    want = og.texture_mapping_bwd(go2, np.concatenate([uv.cpu().numpy(), uv[:1].cpu().numpy()], 0), T)
+    np.testing.assert_allclose(as_float.cpu().numpy(), want, rtol=0, atol=4e-6 * max(np.abs(want).max(), 1.0))
+    assert float(as_float[3].sum()) > 1000
+
+
+@pytest.mark.parametrize("B,H,W,C,T", [(1, 64, 64, 4, 100), (2, 300, 300, 3, 2304), (1, 128, 128, 6, 64)])
+def test_uv_scatter_fixed_small_and_planless(dev, B, H, W, C, T):
+    """ctx_uv_scatter_fixed on rasters below the binning threshold, on an atlas beyond the plan's LDS histogram (T = 2304 > 2272:
+    the plan-less kernel, one int64 atomic per tap) and with more channels than the tile kernel takes: same integer sums."""
+    from contexture_nerf_amd import kal
+    rng = np.random.default_rng(T + C)
+    uv = (rng.random((B, H, W, 2)) * 1.2 - 0.1).astype(np.float32)
+    val = rng.random((B, H, W, C)).astype(np.float32)
+    fidx = np.where(rng.random((B, H, W)) > 0.3, 2, -1).astype(np.int64)
+    assert kal.binned_fits(C, T) == (C <= 4 and T <= 2272)
+    acc = torch.zeros(C, T, T, dtype=torch.int64, device=dev)
+    kal.scatter_fixed(torch.tensor(val, device=dev), torch.tensor(uv, device=dev), torch.tensor(fidx, device=dev), acc)
+    assert np.array_equal(acc.cpu().numpy(), og.uv_scatter_fixed(val, uv, fidx, T, kal.SCATTER_FRAC_BITS))
+
+
+def test_uv_scatter_binned_tiny_and_huge_gradients(dev):
+    """The binned backward picks its fixed-point unit from max|grad_out| of the call: gradients of 1e-8 (a mean-reduced loss, a
+    low-noise DreamTime step) and of 1e+6 come out with the same RELATIVE accuracy as O(1) ones; a non-finite gradient poisons the
+    output instead of being rounded away; a raster rewritten behind a cached plan is detected."""
+    from contexture_nerf_amd import kal
+    rng = np.random.default_rng(5)
+    B, H, W, C, T = 2, 300, 300, 3, 128
+    uv = rng.random((B, H, W, 2)).astype(np.float32)
+    go = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    go[0, :50] *= 1e-4                                       # a wide dynamic range inside one call
+    uvd = torch.tensor(uv, device=dev)
+    ref = og.texture_mapping_bwd(go, uv, T).astype(np.float64)
+    for sc in (1.0, 1e-8, 1e-20, 1e6):
+        g = kal.scatter_add_texture(torch.tensor(go * np.float32(sc), device=dev), uvd, None, torch.zeros(C, T, T, device=dev), binned=True)
+        got = g.cpu().numpy().astype(np.float64) / sc
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err < 2e-6, (sc, err)
+        rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)
+        assert np.median(rel) < 3e-7, (sc, np.median(rel))
+    bad = go.copy(); bad[1, 7, 9, 1] = np.inf
+    g = kal.scatter_add_texture(torch.tensor(bad, device=dev), uvd, None, torch.zeros(C, T, T, device=dev), binned=True)
+    assert bool(torch.isnan(g).all())
+    # stale plan: cache a plan for uvd, then overwrite the raster in place through .data (no version bump)
+    kal.clear_scatter_plans()
+    god = torch.tensor(go, device=dev)
+    g1 = kal.scatter_add_texture(god, uvd, None, torch.zeros(C, T, T, device=dev), binned=True, reuse=True)
+    assert len(kal._PLANS) == 1 and not bool(torch.isnan(g1).any())
+    uvd.data.copy_(torch.tensor(rng.random((B, H, W, 2)).astype(np.float32), device=dev))
+    g2 = kal.scatter_add_texture(god, uvd, None, torch.zeros(C, T, T, device=dev), binned=True, reuse=True)
+    assert bool(torch.isnan(g2).all()), "a rewritten raster must not be scattered along the old plan"
+    plan = next(iter(kal._PLANS.values()))[0]
+    from contexture_nerf_amd import _lib as L
+    assert L.load().ctx_texmap_plan_stale(L.ptr(plan), L.stream()) == 1
+    kal.clear_scatter_plans()
+    assert len(kal._PLANS) == 0
 
 
 @pytest.mark.parametrize("B,H,W,C,T", [(2, 300, 300, 3, 128), (1, 257, 129, 4, 100), (3, 256, 256, 1, 64)])
@@ -674,8 +735,13 @@ def test_uv_scatter_binned_vs_oracle_and_atomics(dev, B, H, W, C, T):
     fidx = np.where(rng.random((B, H, W)) > 0.4, 5, -1).astype(np.int64)
     want = og.texture_mapping_bwd(go * (fidx >= 0)[..., None], uv, T)
     uvd, god, fd = torch.tensor(uv, device=dev), torch.tensor(go, device=dev), torch.tensor(fidx, device=dev)
-    g1 = kal.scatter_add_texture(god, uvd, fd, torch.zeros(C, T, T, device=dev), binned=True)
-    g2 = kal.scatter_add_texture(god, uvd, fd, torch.zeros(C, T, T, device=dev), binned=True)       # plan reused
+    kal.clear_scatter_plans()
+    g1 = kal.scatter_add_texture(god, uvd, fd, torch.zeros(C, T, T, device=dev), binned=True, reuse=True)
+    g2 = kal.scatter_add_texture(god, uvd, fd, torch.zeros(C, T, T, device=dev), binned=True, reuse=True)       # plan reused
+    assert len(kal._PLANS) == 1
+    assert torch.equal(g1, kal.scatter_add_texture(god, uvd, fd, torch.zeros(C, T, T, device=dev), binned=True))   # one-shot plan
+    assert len(kal._PLANS) == 1
+    kal.clear_scatter_plans()
     ga = kal.scatter_add_texture(god, uvd, fd, torch.zeros(C, T, T, device=dev), binned=False)
     assert torch.equal(g1, g2)
     scale = max(1.0, float(np.abs(want).max()))

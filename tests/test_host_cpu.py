@@ -270,7 +270,7 @@ def test_ddpm_scheduler_step_identities():
     g = torch.Generator().manual_seed(0)
     x0, eps = torch.randn(1, 4, 6, 4, generator=g), torch.randn(1, 4, 6, 4, generator=g)
     for pt in ("v_prediction", "epsilon"):
-        sch = DDPMScheduler(prediction_type=pt)
+        sch = DDPMScheduler(prediction_type=pt, clip_sample=False)
         assert sch.init_noise_sigma == 1.0
         sch.set_timesteps(1, timesteps=[515.0])
         assert sch.timesteps.tolist() == [515] and sch.previous_timestep(515) == -1
@@ -288,6 +288,15 @@ def test_ddpm_scheduler_step_identities():
         assert torch.allclose(r0['prev_sample'], x0, atol=2e-4)
     with pytest.raises(ValueError):
         DDPMScheduler().set_timesteps(2, timesteps=[10.0, 20.0])
+    # the defaults `DDPMScheduler.from_config(<EulerAncestral config>)` yields (no clip_sample key there): clip to [-1, 1]
+    sch = DDPMScheduler()
+    assert sch.clip_sample and sch.clip_sample_range == 1.0
+    sch.set_timesteps(1, timesteps=[515.0])
+    ac = float(sch.alphas_cumprod[515]); t = torch.tensor([515])
+    big = 3 * x0
+    xt = sch.add_noise(big, eps, t)
+    r = sch.step(ac ** 0.5 * eps - (1 - ac) ** 0.5 * big, t, xt, generator=torch.Generator().manual_seed(1))
+    assert torch.allclose(r['pred_original_sample'], big.clamp(-1, 1), atol=5e-5) and float(r['pred_original_sample'].abs().max()) <= 1.0
 
 
 def test_safetensors_reader_writer(tmp_path):

@@ -73,7 +73,7 @@ wsb = torch.empty(lib.ctx_texture_mapping_bwd_binned_ws_bytes(3, T), dtype=torch
 report("UV scatter plan (bin pixels by atlas tile; once per raster) B=7 @1200^2",
        timeit(lambda: L.check(lib.ctx_texmap_bwd_plan(L.ptr(uvc), L.ptr(idx), B, H * W, T, L.ptr(plan), L.stream()))), bytes_=B * H * W * (8 + 8) * 2)
 report("texture_mapping bwd binned (LDS tiles, no global float atomics; cached plan) B=7 @1200^2",
-       timeit(lambda: L.check(lib.ctx_texture_mapping_bwd_binned(L.ptr(go), L.ptr(uvc), B, H * W, 3, T, L.ptr(plan), L.ptr(wsb), L.ptr(g), L.stream()))),
+       timeit(lambda: L.check(lib.ctx_texture_mapping_bwd_binned(L.ptr(go), L.ptr(uvc), L.ptr(idx), B, H * W, 3, T, L.ptr(plan), L.ptr(wsb), L.ptr(g), L.stream()))),
        bytes_=B * H * W * (8 + 12 + 8) + 2 * 3 * T * T * 4)
 fnp = fn.permute(0, 2, 1).contiguous()
 idx6 = idx[1:, None].contiguous(); fn6 = fnp[1:].contiguous()
