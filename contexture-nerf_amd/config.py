@@ -53,6 +53,9 @@ class GuideConfig:
     # --- additions of this build (not in the reference): BASELINE.json configs vary the SD image size ---
     sd_image_size: int = 512
     num_inference_steps: int = 50
+    zero123plus_model_dir: Optional[str] = None      # LOCAL directory in the zero123plus pipeline layout (vision_encoder/, feature_extractor_clip/,
+                                                     # tokenizer/, text_encoder/, model_index.json, optionally unet/ vae/ controlnet/): the condition
+                                                     # path of src/zero123plus.py:772-803; nothing is fetched by name
 
 
 @dataclass

@@ -139,6 +139,7 @@ class StableDiffusion:
             self.text_embeddings, self.guidance_scale = text_embeddings, guidance_scale
             scheduler.set_timesteps(num_inference_steps)
             shape = (text_embeddings.shape[0] // 2, unet.in_channels - 1, depth_mask.shape[2], depth_mask.shape[3])
+            noise = None                                                 # `noise` of the reference's sample(): stays None when latents is None
             if latents is None:
                 latents = torch.randn(shape, device=sd.device)
                 timesteps = scheduler.timesteps
@@ -154,6 +155,8 @@ class StableDiffusion:
                 else:
                     latents = scheduler.add_noise(latents, noise, latent_timestep)
             self.latents, self.timesteps, self.i = latents, timesteps, 0
+            self.noise = noise
+            self.on_step = None                                          # intermediate_vis hook: called with (t, latents) before the step
             self.depth2 = torch.cat([depth_mask] * 2)
 
         def done(self):
@@ -165,6 +168,8 @@ class StableDiffusion:
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
             x = torch.cat([latent_model_input, self.depth2], dim=1)
             noise_pred = self.unet(x, float(t), encoder_hidden_states=self.text_embeddings)['sample']
+            if self.on_step is not None:
+                self.on_step(t, self.latents, self.noise)
             self.latents = self.scheduler.step_cfg(noise_pred, self.guidance_scale, int(t), self.latents)['prev_sample']
             self.i += 1
 
@@ -194,6 +199,8 @@ class StableDiffusion:
         with torch.no_grad():
             job = StableDiffusion._Denoise(self, self.unet, self.scheduler, text_embeddings, latents, depth_mask, strength,
                                            num_inference_steps, update_mask, fixed_seed, guidance_scale)
+            if intermediate_vis:
+                job.on_step = lambda t, lat, noise: intermediate_results.append(self._vis_step(t, lat, noise))
             while not job.done():
                 job.advance()
             target_latents = job.latents
@@ -201,6 +208,18 @@ class StableDiffusion:
         if latent_mode:
             return target_rgb, target_latents
         return target_rgb, intermediate_results
+
+    def _vis_step(self, t, latents, noise):
+        """`intermediate_vis` of img2img_step (stable_diffusion_depth.py:500-511, LogConfig.vis_diffusion_steps): the x0 estimate
+        the reference decodes at every step — `(latents - sigma_t * noise) / alpha_t` with the loop's INITIAL `noise` tensor (not the
+        step's prediction; mirrored as written) — through the VAE, as an 8-bit PIL image."""
+        from PIL import Image
+        ac = self.scheduler.alphas_cumprod
+        a_t, s_t = float(torch.sqrt(ac[int(t)])), float(torch.sqrt(1 - ac[int(t)]))
+        vis_latents = (latents - s_t * noise) / a_t             # noise is None when latents was None: a TypeError, as in the reference
+        image = self.decode_latents(vis_latents)
+        image = image.cpu().permute(0, 2, 3, 1).numpy()
+        return Image.fromarray((image[0] * 255).round().astype("uint8"))
 
     def img2img_step_multi(self, calls):
         """Several img2img_step calls (views of one mesh) with their denoise loops in flight together: one HIP stream, one

@@ -37,12 +37,41 @@ class ConTEXTure:
         self.train_views = list(ds(self.cfg.render, self.device))
         self.view_weights = None
         self.back_im = torch.full((3, 64, 64), 0.5, device=self.device)
+        self.view_dirs = ['front', 'left', 'back', 'right', 'overhead', 'bottom']       # trainer.py:138
+        self.text_string = None
 
     def _offset_phi(self, phi):
         """phi - front_offset, wrapped into [0, 2 pi) (trainer.py:378-380, 974-976): ONE helper for define_view_weights and
         paint_viewpoint, so that view-weight masks and painted views always share their cameras."""
         phi = float(phi) - math.radians(self.cfg.render.front_offset)
         return float(phi + 2 * math.pi if phi < 0 else phi)
+
+    # ---- trainer.py:316-344 ----------------------------------------------------------------------------------
+    def calc_text_embeddings(self):
+        """-> (text_z, text_string) with the reference's three shapes: under use_zero123plus a pair [prompt, prompt + ", front view"]
+        (and the assert that aborts the shipped YAMLs with append_direction: True, SURVEY section 5.6 defect i); without
+        append_direction one embedding; with it one per view direction (`text.format(dir)`)."""
+        ref_text = self.cfg.guide.text
+        if self.cfg.guide.use_zero123plus:
+            assert not self.cfg.guide.append_direction, "append_direction should be False when use_zero123plus is True"
+            text_string = [ref_text, ref_text + ", front view"]
+            return [self.diffusion.get_text_embeds([t], negative_prompt=None) for t in text_string], text_string
+        if not self.cfg.guide.append_direction:
+            return self.diffusion.get_text_embeds([ref_text]), ref_text
+        text_string = [ref_text.format(d) for d in self.view_dirs]
+        return [self.diffusion.get_text_embeds([t], negative_prompt=None) for t in text_string], text_string
+
+    def _text_for(self, data):
+        """The embedding paint_viewpoint conditions this view on (trainer.py:1018-1031).  A tensor assigned to `self.text_z` by
+        the caller (benches, tests) is used as is."""
+        if self.text_z is None:
+            self.text_z, self.text_string = self.calc_text_embeddings()
+        if isinstance(self.text_z, torch.Tensor):
+            return self.text_z
+        if self.cfg.guide.use_zero123plus:
+            return self.text_z[1]
+        d = data['dir']
+        return self.text_z[int(d.reshape(-1)[0]) if isinstance(d, torch.Tensor) else int(d)]
 
     # ---- trainer.py:370-415 ----------------------------------------------------------------------------------
     def define_view_weights(self, view_ids=None):
@@ -90,10 +119,10 @@ class ConTEXTure:
         min_h, min_w, max_h, max_w = utils.get_nonzero_region_tuple(object_mask[0, 0])
         crop = lambda x: x[:, :, min_h:max_h, min_w:max_w]
         cropped_rgb_render, cropped_depth_render, cropped_update_mask = crop(rgb_render), crop(depth_render), crop(object_mask)
-        text_z = self.text_z if self.text_z is not None else self.diffusion.get_text_embeds([self.cfg.guide.text])
+        text_z = self._text_for(data)
         kw = dict(text_embeddings=text_z, inputs=cropped_rgb_render.detach(), original_depth_mask=cropped_depth_render.detach(),
                   guidance_scale=self.cfg.guide.guidance_scale, strength=1.0, update_mask=cropped_update_mask,
-                  fixed_seed=self.cfg.optim.seed, intermediate_vis=False,
+                  fixed_seed=self.cfg.optim.seed, intermediate_vis=self.cfg.log.vis_diffusion_steps,
                   num_inference_steps=num_inference_steps or self.cfg.guide.num_inference_steps,
                   image_size=image_size or self.cfg.guide.sd_image_size)
         ctx = dict(render_cache=render_cache, z_normals=z_normals, rgb_render=rgb_render, object_mask=object_mask, background=background,
@@ -248,30 +277,52 @@ class ConTEXTure:
         return n
 
     # ---- trainer.py:296-315 ---------------------------------------------------------------------------------
-    def init_zero123plus(self, unet=None, controlnet=None, vae=None, unet_config=None, vae_config=None):
+    def init_zero123plus(self, unet=None, controlnet=None, vae=None, unet_config=None, vae_config=None, model_dir=None):
         """The Zero123++ stack the reference assembles from the hub (remote pipeline `sudo-ai/zero123plus-pipeline` + depth ControlNet
         at conditioning scale 2, scheduler swapped for DDPMScheduler): here the same wrappers over the HIP engines —
         DepthControlUNet(RefOnlyNoisedUNet(UNet in_channels 4)), AutoencoderKL, DDPMScheduler (v-prediction) as the pipeline's
-        scheduler.  Offline the weights are seeded random-init (or engines / state loaded by the caller); the CLIP-vision
-        `global_embeds` and the empty-prompt text embedding have no weights here and are a seeded random `prompt_embeds`."""
+        scheduler.  Offline the weights are seeded random-init (or engines / state loaded by the caller).  model_dir (or
+        cfg.guide.zero123plus_model_dir): a LOCAL directory in the pipeline's layout; its `vision_encoder/`, `feature_extractor_clip/`,
+        `tokenizer/`, `text_encoder/` and `model_index.json: ramping_coefficients` give the condition path of
+        src/zero123plus.py:772-803 (`zero123plus.ConditionEncoder`), and `unet/`, `vae/`, `controlnet/` safetensors files are loaded
+        when present.  Without one, a seeded random `prompt_embeds` stands in for encode_prompt("") + global_embeds * ramp."""
+        import os
         from .unet import UNet2DConditionModel, ControlNetModel, SD2_DEPTH
         from .vae import AutoencoderKL
         from .scheduler import DDPMScheduler
         from .zero123plus import RefOnlyNoisedUNet, DepthControlUNet, Zero123PlusPipeline
         ucfg = dict(SD2_DEPTH, in_channels=4) if unet_config is None else dict(unet_config)
         seed = self.cfg.optim.seed
-        unet = unet if unet is not None else UNet2DConditionModel(ucfg, device=self.device, seed=seed + 11)
-        controlnet = controlnet if controlnet is not None else ControlNetModel(ucfg, device=self.device, seed=seed + 12)
-        vae = vae if vae is not None else AutoencoderKL(vae_config, device=self.device, seed=seed + 13)
+        model_dir = model_dir if model_dir is not None else getattr(self.cfg.guide, 'zero123plus_model_dir', None)
+
+        def local(sub):
+            f = os.path.join(str(model_dir), sub, 'diffusion_pytorch_model.safetensors') if model_dir else None
+            return f if f and os.path.exists(f) else None
+        if unet is None:
+            unet = UNet2DConditionModel.from_file(local('unet'), ucfg, device=self.device) if local('unet') else \
+                UNet2DConditionModel(ucfg, device=self.device, seed=seed + 11)
+        if controlnet is None:
+            controlnet = ControlNetModel(ucfg, device=self.device, seed=seed + 12, init=not local('controlnet'))
+            if local('controlnet'):
+                controlnet.load_file(local('controlnet'))
+        if vae is None:
+            vae = AutoencoderKL.from_file(local('vae'), device=self.device) if local('vae') else AutoencoderKL(vae_config, device=self.device, seed=seed + 13)
         # trainer.py:306-310: the pipeline's scheduler is replaced by a DDPMScheduler BEFORE prepare(), so RefOnlyNoisedUNet's
         # val_sched (used in eval mode to noise the condition latent) is that same DDPM object
         psched = DDPMScheduler(prediction_type="v_prediction")
         stack = DepthControlUNet(RefOnlyNoisedUNet(unet, DDPMScheduler(prediction_type="v_prediction"), psched).eval(), controlnet,
                                  conditioning_scale=2.0).eval()
-        self.zero123plus = Zero123PlusPipeline(vae, stack, psched)
+        from .zero123plus import ConditionEncoder
+        cenc = None
+        if model_dir and os.path.isdir(os.path.join(str(model_dir), 'vision_encoder')):
+            cenc = ConditionEncoder(model_dir, device=self.device)
+        self.zero123plus = Zero123PlusPipeline(vae, stack, psched, condition_encoder=cenc)
         self.zero123plus.inpaint_unet_source = self.diffusion          # trainer.py:312, resolved on first use
-        g = torch.Generator().manual_seed(seed + 14)
-        self.zero123plus_prompt_embeds = torch.randn(1, 77, ucfg['cross_attention_dim'], generator=g).to(self.device)
+        if cenc is None:
+            g = torch.Generator().manual_seed(seed + 14)
+            self.zero123plus_prompt_embeds = torch.randn(1, 77, ucfg['cross_attention_dim'], generator=g).to(self.device)
+        else:
+            self.zero123plus_prompt_embeds = None                      # computed from the condition image in paint_zero123plus
         return self.zero123plus
 
     # ---- trainer.py:545-911 ---------------------------------------------------------------------------------
@@ -307,6 +358,11 @@ class ConTEXTure:
             cond_image = cond * 2 - 1
             depth_grid = sds.build_depth_grid(depth_maps, object_masks, size=tile)
             boxes = [utils.get_nonzero_region_tuple(object_masks[j, 0]) for j in range(1, B)]
+            if getattr(pipe, 'condition_encoder', None) is not None:
+                # src/zero123plus.py:772-803, once per mesh (the pipeline recomputes the same tensors on every call in the reference):
+                # encode_prompt("") + vision_encoder(feature_extractor_clip(cond)).image_embeds * ramping_coefficients
+                pe, neg = pipe.condition_encoder.prompt_embeds(cond)
+                self.zero123plus_prompt_embeds, pipe.negative_prompt_embeds = pe.to(self.device), neg.to(self.device)
         self._sds_setup = dict(cond_image=cond_image, depth_grid=depth_grid, boxes=boxes, render_cache=render_cache)
         params = [p for p in self.texture_mlp.parameters()]
         optimizer = torch.optim.Adam(params, lr=1e-5, betas=(0.9, 0.99), eps=1e-15)

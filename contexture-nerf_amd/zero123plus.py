@@ -11,10 +11,15 @@ src/training/trainer.py:296-315); what is built here is the part that sits on th
 
   Zero123PlusPipeline.__call__ / run_sd_pipeline's denoising loop (:411-746, 748-833) over tensors: condition-image latent,
       CFG pair, EulerAncestral steps (or the explicit one-step schedule of the SDS loop) with `callback_on_step_end` exposing
-      `noise_pred`, unscale_latents -> vae.decode -> unscale_image.  The PIL / CLIP preprocessing and the vision / text encoders are
-      not part of it (no weights offline): `prompt_embeds` / `global_embeds` come in as tensors (seeded stand-ins otherwise); the
-      inpaint / blend extension of run_sd_pipeline (:436-440, 650-708) is not built.
+      `noise_pred`, unscale_latents -> vae.decode -> unscale_image, incl. ConTEXTure's inpaint / blend extension (:436-440, 650-708).
+
+  ConditionEncoder  (:772-803): the condition image's CLIP path — `feature_extractor_clip` -> `vision_encoder(...).image_embeds` ->
+      `global_embeds`, added with the pipeline's `ramping_coefficients` to the text encoding of the (empty) prompt — read from a
+      LOCAL pipeline directory with transformers (`local_files_only`): once per painted mesh, off the per-step path.  Without such a
+      directory (nothing can be fetched offline) `prompt_embeds` / `global_embeds` come in as tensors or seeded stand-ins.
 """
+import json
+import os
 import types
 import torch
 from . import _lib as L
@@ -85,6 +90,63 @@ class DepthControlUNet(torch.nn.Module):
                          cross_attention_kwargs=cross_attention_kwargs)
 
 
+class ConditionEncoder:
+    """The condition-image / prompt encoders of the Zero123++ pipeline (src/zero123plus.py:772-803; the pipeline's `model_index.json`
+    names them `feature_extractor_clip`, `vision_encoder`, `tokenizer`, `text_encoder` and carries `ramping_coefficients`), read
+    from a LOCAL directory in that layout through transformers with `local_files_only=True` — nothing is fetched by name.
+    Host-side torch modules evaluated once per mesh; not part of the denoise hot path."""
+
+    def __init__(self, model_dir, device='cpu'):
+        from transformers import CLIPImageProcessor, CLIPVisionModelWithProjection, CLIPTextModel, CLIPTokenizer
+        d = str(model_dir)
+        for sub in ('feature_extractor_clip', 'vision_encoder'):
+            if not os.path.isdir(os.path.join(d, sub)):
+                raise L.CtxError(f"ConditionEncoder: {d} has no {sub}/ (expected the zero123plus pipeline layout)")
+        self.device = device
+        idx = os.path.join(d, 'model_index.json')
+        self.ramping_coefficients = json.load(open(idx)).get('ramping_coefficients') if os.path.exists(idx) else None
+        self.feature_extractor_clip = CLIPImageProcessor.from_pretrained(os.path.join(d, 'feature_extractor_clip'), local_files_only=True)
+        self.vision_encoder = CLIPVisionModelWithProjection.from_pretrained(os.path.join(d, 'vision_encoder'), local_files_only=True).to(device).eval()
+        self.tokenizer = self.text_encoder = None
+        if os.path.isdir(os.path.join(d, 'tokenizer')) and os.path.isdir(os.path.join(d, 'text_encoder')):
+            self.tokenizer = CLIPTokenizer.from_pretrained(os.path.join(d, 'tokenizer'), local_files_only=True)
+            self.text_encoder = CLIPTextModel.from_pretrained(os.path.join(d, 'text_encoder'), local_files_only=True).to(device).eval()
+
+    @torch.no_grad()
+    def global_embeds(self, image01):
+        """image01 [1,3,H,W] in [0,1] (the condition RGB, transparent part already greyed by to_rgb_image) -> [1,1,D]:
+        `feature_extractor_clip(images=image).pixel_values` -> `vision_encoder(...).image_embeds.unsqueeze(-2)` (:773, 784-786).  The
+        processor sees the same 8-bit HWC pixels a PIL image would hand it."""
+        arr = (image01[0].detach().float().clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+        pv = self.feature_extractor_clip(images=arr, return_tensors='pt').pixel_values.to(self.device)
+        return self.vision_encoder(pv, output_hidden_states=False).image_embeds.unsqueeze(-2).float()
+
+    @torch.no_grad()
+    def encode_prompt(self, prompt=""):
+        """`self.encode_prompt(prompt, device, 1, False)[0]` (:788-794): the text encoder's last hidden state, padded to max length."""
+        if self.text_encoder is None:
+            raise L.CtxError("ConditionEncoder: the directory carries no tokenizer/ + text_encoder/")
+        tok = self.tokenizer
+        ids = tok([prompt] if isinstance(prompt, str) else list(prompt), padding='max_length', max_length=tok.model_max_length,
+                  truncation=True, return_tensors='pt').input_ids
+        return self.text_encoder(ids.to(self.device))[0].float()
+
+    def ramp(self, n_tokens, dtype=torch.float32):
+        rc = self.ramping_coefficients
+        if rc is None:
+            raise L.CtxError("ConditionEncoder: model_index.json carries no ramping_coefficients")
+        if len(rc) != n_tokens:
+            raise L.CtxError(f"ConditionEncoder: {len(rc)} ramping coefficients for {n_tokens} prompt tokens")
+        return torch.tensor(rc, dtype=dtype, device=self.device).unsqueeze(-1)
+
+    def prompt_embeds(self, image01, prompt=""):
+        """-> (encoder_hidden_states [1,L,D] = encode_prompt(prompt) + global_embeds * ramp  (:800-803),
+               negative [1,L,D] = encode_prompt("") — what run_sd_pipeline's own encode_prompt puts in the unconditional half (:582-598))."""
+        ehs = self.encode_prompt(prompt)
+        ge = self.global_embeds(image01)
+        return ehs + ge * self.ramp(ehs.shape[1], ehs.dtype), self.encode_prompt("")
+
+
 class Zero123PlusPipeline:
     """Tensor-level mirror of the pipeline's __call__ (src/zero123plus.py:748-833) and of the denoising loop of run_sd_pipeline
     (:604-746, without the inpaint / blend branch).  unet = DepthControlUNet(RefOnlyNoisedUNet(...)) or RefOnlyNoisedUNet(...)."""
@@ -101,20 +163,26 @@ class Zero123PlusPipeline:
     def inpaint_unet(self, v):
         self.__dict__['_inpaint_unet'] = v
 
-    def __init__(self, vae, unet, scheduler, ramping_coefficients=None):
+    def __init__(self, vae, unet, scheduler, ramping_coefficients=None, condition_encoder=None):
         self.vae, self.unet, self.scheduler = vae, unet, scheduler
+        self.condition_encoder = condition_encoder
+        if ramping_coefficients is None and condition_encoder is not None:
+            ramping_coefficients = condition_encoder.ramping_coefficients
         self.ramping_coefficients = ramping_coefficients
 
     def encode_condition_image(self, image):
         return self.vae.encode(image).latent_dist.sample()
 
     @torch.no_grad()
-    def __call__(self, image, prompt_embeds=None, global_embeds=None, guidance_scale=4.0, depth_image=None, output_type="pt",
+    def __call__(self, image, prompt_embeds=None, global_embeds=None, prompt="", negative_prompt_embeds=None, guidance_scale=4.0,
+                 depth_image=None, output_type="pt",
                  width=640, height=960, num_inference_steps=28, timesteps=None, latents=None, generator=None,
                  callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",),
                  use_inpaint=False, use_blending=False, latent_mask_grid=None, latent_renders_grid=None, masked_input_latents=None):
         """image: [1,3,H,W] in [-1,1] (already resized / normalised for the VAE); depth_image: [1,3,height,width] in [0,1];
-        prompt_embeds [1,77,D] (and optionally global_embeds [1,1,D], added with the ramping coefficients as :802-803).
+        prompt_embeds [1,77,D] (and optionally global_embeds [1,1,D], added with the ramping coefficients as :802-803); with a
+        `condition_encoder` (a local pipeline directory) and no prompt_embeds, both come from the CLIP vision / text encoders as in
+        the reference, and the unconditional half is the encoding of "" (zeros when there is no text encoder).
         -> images [1,3,height,width] in [0,1] (output_type 'pt') or the unscaled latents ('latent').
         ConTEXTure's inpaint / blend extension of run_sd_pipeline (src/zero123plus.py:436-440, 650-708), as the spec text has it:
         use_blending — before every step outside the inpaint range the latents are re-anchored outside the mask,
@@ -129,6 +197,15 @@ class Zero123PlusPipeline:
         cond_lat = self.encode_condition_image(image)
         if do_cfg:
             cond_lat = torch.cat([self.encode_condition_image(torch.zeros_like(image)), cond_lat])
+        ce = self.condition_encoder
+        if negative_prompt_embeds is None:                       # precomputed once per mesh by the SDS loop (trainer.paint_zero123plus)
+            negative_prompt_embeds = getattr(self, 'negative_prompt_embeds', None)
+        if prompt_embeds is None and ce is not None:             # :772-803 through the local encoders; `image` is feature_extractor_vae's
+            if global_embeds is None:                            # 2x - 1 of the condition RGB, so (image + 1) / 2 is what the CLIP processor saw
+                global_embeds = ce.global_embeds((image + 1) / 2).to(dev)
+            prompt_embeds = ce.encode_prompt(prompt).to(dev)
+            if negative_prompt_embeds is None and do_cfg:
+                negative_prompt_embeds = ce.encode_prompt("").to(dev)
         if prompt_embeds is None:
             g = torch.Generator().manual_seed(0)
             prompt_embeds = torch.randn(1, 77, cfg['cross_attention_dim'], generator=g).to(dev)
@@ -136,8 +213,9 @@ class Zero123PlusPipeline:
             ramp = torch.as_tensor(self.ramping_coefficients if self.ramping_coefficients is not None else [0.0] * prompt_embeds.shape[1],
                                    dtype=prompt_embeds.dtype, device=dev).unsqueeze(-1)
             prompt_embeds = prompt_embeds + global_embeds * ramp
-        if do_cfg:                                               # negative prompt embeds first (encode_prompt's ordering)
-            prompt_embeds = torch.cat([torch.zeros_like(prompt_embeds), prompt_embeds])
+        if do_cfg:                                               # negative prompt embeds first (encode_prompt's ordering, :582-598)
+            neg = negative_prompt_embeds if negative_prompt_embeds is not None else torch.zeros_like(prompt_embeds)     # no text encoder: zeros
+            prompt_embeds = torch.cat([neg.to(prompt_embeds.dtype), prompt_embeds])
         cak = dict(cond_lat=cond_lat)
         if hasattr(self.unet, 'controlnet'):
             if depth_image is None:
