@@ -4,9 +4,12 @@
 
 Out of scope here: spectral/axis augmentations, Laplacian helpers, mesh export.
 UV atlases: meshes that carry UVs use them; for meshes without UVs the reference calls xatlas (C++,
-absent offline) — `grid_atlas` below is a deterministic stand-in (two triangles per grid cell); its layout
-cannot match xatlas and is documented as such in DESIGN.md.
+absent offline) — `atlas.chart_atlas` (connected charts grown over face adjacency, planar projection, skyline
+packing with a gutter) is the deterministic stand-in; its layout cannot match xatlas and is documented as such
+in DESIGN.md.  `grid_atlas` below (two triangles per grid cell, a seam on every edge) remains as the fallback
+selected by CTX_ATLAS=grid.
 """
+import json
 import math
 import os
 import numpy as np
@@ -30,6 +33,22 @@ def grid_atlas(n_faces, margin=0.08):
     vt = (tri + np.stack([cx, cy], -1)[:, None, :]) / n
     ft = np.arange(3 * n_faces, dtype=np.int64).reshape(n_faces, 3)
     return torch.from_numpy(vt.reshape(-1, 2).astype(np.float32)), torch.from_numpy(ft)
+
+
+_ATLAS_MEMO = {}
+
+
+def _chart_atlas_memo(v_np, f_np, resolution):
+    """atlas.chart_atlas with an in-process memo keyed by the mesh bytes (a batch that repeats a mesh, or several trainers over
+    one mesh, unwrap it once; the generator is deterministic)."""
+    import hashlib
+    from .atlas import chart_atlas
+    key = (hashlib.sha1(np.ascontiguousarray(v_np).tobytes() + np.ascontiguousarray(f_np).tobytes()).hexdigest(), int(resolution))
+    if key not in _ATLAS_MEMO:
+        vt_np, ft_np = chart_atlas(v_np, f_np, resolution=int(resolution))
+        _ATLAS_MEMO[key] = (torch.from_numpy(vt_np), torch.from_numpy(ft_np))
+    vt, ft = _ATLAS_MEMO[key]
+    return vt.clone(), ft.clone()
 
 
 class TexturedMeshModel(torch.nn.Module):
@@ -67,16 +86,42 @@ class TexturedMeshModel(torch.nn.Module):
         if self.mesh.vt is not None and self.mesh.ft is not None and self.mesh.vt.shape[0] > 0 and self.mesh.ft.numel() > 0 \
                 and self.mesh.ft.min() > -1 and float((self.mesh.vt.max(0).values - self.mesh.vt.min(0).values).min()) > 0:
             vt, ft = self.mesh.vt.to(self.device), self.mesh.ft.to(self.device)
-        elif cache_path is not None and os.path.exists(vt_cache) and os.path.exists(ft_cache):
+        elif cache_path is not None and os.path.exists(vt_cache) and os.path.exists(ft_cache) and self._cache_meta_ok(cache_path):
             vt = torch.load(vt_cache, weights_only=True).to(self.device)
             ft = torch.load(ft_cache, weights_only=True).to(self.device)
         else:
-            vt, ft = grid_atlas(self.mesh.faces.shape[0])
+            if os.environ.get("CTX_ATLAS", "chart") == "grid":
+                vt, ft = grid_atlas(self.mesh.faces.shape[0])
+            else:                                                   # the xatlas stand-in (textured_mesh.py:392-404)
+                vt, ft = _chart_atlas_memo(self.mesh.vertices.detach().cpu().numpy(), self.mesh.faces.cpu().numpy(), self.texture_resolution)
             vt, ft = vt.to(self.device), ft.to(self.device)
             if cache_path is not None:
                 os.makedirs(str(cache_path), exist_ok=True)
-                torch.save(vt.cpu(), vt_cache); torch.save(ft.cpu(), ft_cache)
+                # every rank of a job unwraps the same (deterministic) atlas: write through temporaries and rename, so that a
+                # peer never reads a half-written file
+                suffix = f'.tmp{os.getpid()}'
+                torch.save(vt.cpu(), vt_cache + suffix); os.replace(vt_cache + suffix, vt_cache)
+                torch.save(ft.cpu(), ft_cache + suffix); os.replace(ft_cache + suffix, ft_cache)
+                meta = os.path.join(str(cache_path), 'atlas_meta.json')
+                with open(meta + suffix, 'w') as fh:
+                    json.dump(self._cache_meta(), fh)
+                os.replace(meta + suffix, meta)
         return vt, ft
+
+    def _cache_meta(self):
+        return {"generator": os.environ.get("CTX_ATLAS", "chart"), "resolution": int(self.texture_resolution),
+                "faces": int(self.mesh.faces.shape[0])}
+
+    def _cache_meta_ok(self, cache_path):
+        """A cached atlas is reused when it was generated for this face count, generator and atlas resolution (the gutter is in
+        texels).  A cache without the side file (written by another tool, as the reference's xatlas cache) is taken as is."""
+        f = os.path.join(str(cache_path), 'atlas_meta.json')
+        if not os.path.exists(f):
+            return True
+        try:
+            return json.load(open(f)) == self._cache_meta()
+        except Exception:
+            return False
 
     def get_texture_map(self):
         """-> (texture [1,3,res,res] in [0,1], mlp_output [res*res,3]); uv grid, embedding, MLP and (tanh+1)/2 fused."""

@@ -8,6 +8,7 @@ direct UV-scatter form `project_back_scatter` stands in, parity unpinned), the e
 `evaluate`, `full_eval`, :913-968, 1119-1157) and the mesh export.  Not built: wandb/loguru logging, the mp4 mux.
 """
 import math
+import os
 import torch
 import torch.nn.functional as F
 from . import _lib as L
@@ -28,7 +29,9 @@ class ConTEXTure:
         utils.seed_everything(self.cfg.optim.seed)
         self.uv_embedder, input_ch = get_embedder(10)
         self.texture_mlp = NeRF2D(D=8, W=256, input_ch=input_ch, output_ch=3, skips=[4]).to(self.device)
-        self.mesh_model = TexturedMeshModel(self.cfg.guide, render_grid_size=self.cfg.render.train_grid_size,
+        # trainer.py:253-255: the UV unwrap of a mesh without texture coordinates is cached under cache/<mesh stem>/
+        cache_path = None if mesh_arrays is not None else os.path.join('cache', os.path.splitext(os.path.basename(str(self.cfg.guide.shape_path)))[0])
+        self.mesh_model = TexturedMeshModel(self.cfg.guide, render_grid_size=self.cfg.render.train_grid_size, cache_path=cache_path,
                                             texture_resolution=self.cfg.guide.texture_resolution, device=self.device,
                                             texture_mlp=self.texture_mlp, uv_embedder=self.uv_embedder, mesh_arrays=mesh_arrays)
         self.diffusion = diffusion

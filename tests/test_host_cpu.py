@@ -485,3 +485,35 @@ def test_zero123plus_condition_encoder_from_local_directory(tmp_path):
     (d / "model_index.json").write_text(json.dumps({"ramping_coefficients": ramp[:5]}))
     with pytest.raises(L.CtxError, match="ramping coefficients"):
         ConditionEncoder(str(d)).prompt_embeds(img)
+
+
+@pytest.mark.parametrize("name", ["nascar", "bunny", "blub_no_texture"])
+def test_chart_atlas_generator(meshes, name):
+    """atlas.chart_atlas, the stand-in for the reference's xatlas call (src/models/textured_mesh.py:392-404), on the bundled meshes
+    without UVs: every face owns a non-degenerate, consistently oriented triangle inside [0,1]^2; no texel centre of the 1024^2
+    atlas is claimed by two faces; >= 0.6 of the texels are used; neighbours on a smooth surface share their UV edge (far fewer
+    seam edges than faces); bounded stretch; deterministic."""
+    from contexture_nerf_amd.atlas import chart_atlas, rasterize_uv_counts
+    v, f = meshes[name + '_v'], meshes[name + '_f'].astype(np.int64)
+    vt, ft, info = chart_atlas(v, f, resolution=1024, gutter=2, return_info=True)
+    F = f.shape[0]
+    assert vt.dtype == np.float32 and ft.shape == (F, 3) and ft.min() == 0 and ft.max() == vt.shape[0] - 1
+    assert vt.min() >= 0.0 and vt.max() <= 1.0
+    p = vt[ft].astype(np.float64)
+    area2 = (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1]) - (p[:, 2, 0] - p[:, 0, 0]) * (p[:, 1, 1] - p[:, 0, 1])
+    e0, e1 = v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
+    a3 = np.linalg.norm(np.cross(e0, e1), axis=1)
+    assert (np.abs(area2[a3 > 1e-12]) > 0).all()
+    # 2-D area / 3-D area = texel density^2 * cos(angle to the chart plane): within [cos(50 deg), 1] of the global density
+    ratio = np.abs(area2) * 1024 ** 2 / np.maximum(a3, 1e-30) / info['texels_per_unit'] ** 2
+    ok = a3 > 1e-10
+    assert ratio[ok].max() <= 1.0 + 1e-2 and ratio[ok].min() >= np.cos(np.deg2rad(50.0)) - 1e-2        # vt is float32
+    cnt, _ = rasterize_uv_counts(vt, ft, 1024)
+    assert int(cnt.max()) == 1 and info['overlap_texels'] == 0
+    used = float((cnt > 0).mean())
+    assert used >= 0.6 and abs(used - info['utilisation']) < 1e-4, used
+    assert info['seam_edges'] < 0.2 * (info['seam_edges'] + info['interior_edges']) and info['charts'] < F // 20
+    print(f"{name}: {info}")
+    if name == "bunny":                                                       # deterministic (checked on the quickest mesh)
+        vt2, ft2 = chart_atlas(v, f, resolution=1024, gutter=2)
+        assert np.array_equal(vt, vt2) and np.array_equal(ft, ft2)
