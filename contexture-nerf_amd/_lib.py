@@ -70,6 +70,9 @@ SIGNATURES = {
     "ctx_unet_forward_ref": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "ctx_unet_set_residual_fp32": (_i32, [_vp, _i32]),
     "ctx_unet_stats": (_i32, [_vp, _i32, _vp, _vp]),
+    "ctx_unet_set_taps": (_i32, [_vp, _vp, _i64]),
+    "ctx_unet_tap_count": (_i32, [_vp]),
+    "ctx_unet_tap_info": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "ctx_vae_create": (_vp, [_vp]),
     "ctx_vae_destroy": (None, [_vp]),
     "ctx_vae_param_count": (_i32, [_vp]),

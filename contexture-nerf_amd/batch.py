@@ -48,6 +48,9 @@ class MeshBatchPainter:
         contrib = [torch.zeros(4, T, T, dtype=torch.int64, device=self.device) for _ in self.trainers]   # 2^-32 fixed point
         diffusion = self.trainers[0].diffusion
         infl = max(1, int(getattr(self.trainers[0].cfg.optim, 'views_in_flight', 3)))
+        vpe = int(getattr(self.trainers[0].cfg.optim, 'views_per_eval', 0))
+        if vpe > 1 and hasattr(diffusion, 'img2img_step_batched'):
+            infl = vpe                                                # one lockstep UNet evaluation of batch 2 x vpe per group
         if not hasattr(diffusion, 'img2img_step_multi'):
             infl = 1
         for j in range(0, len(mine), infl):
@@ -56,7 +59,9 @@ class MeshBatchPainter:
             for (m, v) in grp:
                 tr = self.trainers[m]
                 preps.append(tr._paint_prepare(tr.train_views[self.view_ids[v]], image_size, num_inference_steps))
-            if len(grp) > 1:
+            if vpe > 1 and hasattr(diffusion, 'img2img_step_batched'):
+                outs = diffusion.img2img_step_batched([p[0] for p in preps], views_per_eval=vpe)
+            elif len(grp) > 1:
                 outs = diffusion.img2img_step_multi([p[0] for p in preps])
             else:
                 kw = dict(preps[0][0])

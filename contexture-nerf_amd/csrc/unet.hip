@@ -96,6 +96,20 @@ struct ctx_unet {
     // branch, and the skip copies of those — in fp32; GEMM / conv operands stay fp16 (cast on the way in), accumulators fp32
     bool res32 = false;
     void *allocS(size_t n) { return alloc(n * (res32 ? 4 : 2)); }          // a residual-stream tensor of n elements
+    // measurement aid (tools/precision_attribution.py): copy every block's output (fp16 NHWC) into a caller buffer
+    struct Tap { size_t off; int rows, C; };
+    f16 *tap_buf = nullptr;
+    size_t tap_cap = 0, tap_cursor = 0;        // elements
+    std::vector<Tap> taps;
+    void tap(const void *x, int rows, int C)
+    {
+        if (!tap_buf || res32) return;
+        const size_t n = (size_t)rows * C;
+        Tap t = {tap_cursor, rows, C};
+        taps.push_back(t);
+        if (!dry && rc == 0 && tap_cursor + n <= tap_cap) (void)hipMemcpyAsync(tap_buf + tap_cursor, x, n * 2, hipMemcpyDeviceToDevice, s);
+        tap_cursor += n;
+    }
 
     size_t walloc(size_t n) { size_t o = wtop; wtop += (n + 127) / 128 * 128; return o; }
     size_t add(const std::string &name, std::vector<int64_t> shp, int kind, size_t dst, int a = 0, int b = 0)
@@ -621,6 +635,7 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
     const int *ch = c.block_out_channels;
     u->top = 0; u->peak = 0; u->rc = 0;
     u->ref_k = 0; u->ref_cursor = 0;
+    u->taps.clear(); u->tap_cursor = 0;
     if (u->ref_mode == 1) u->ref_slots.clear();
     for (int k = 0; k < 3; ++k) { u->launches[k] = 0; u->flops[k] = 0; }
     FwdCtx f; f.B = B; f.L = L;
@@ -693,6 +708,7 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
     struct Skip { void *p; int C, h, w; };
     std::vector<Skip> skips;
     skips.push_back({x, ch[0], h, w});
+    u->tap(x, B * h * w, ch[0]);
     int cur = ch[0];
     for (int i = 0; i < n; ++i) {
         LevelP &Lv = u->down[i];
@@ -703,9 +719,11 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
                 size_t mark = u->top;
                 void *t = u->allocS((size_t)B * h * w * cout);
                 run_resnet(u, f, Lv.res[j], x, h, w, t);
+                u->tap(t, B * h * w, cout);
                 run_transformer(u, f, Lv.tr[j], t, h, w, o);
                 u->top = mark;
             } else run_resnet(u, f, Lv.res[j], x, h, w, o);
+            u->tap(o, B * h * w, cout);
             x = o; cur = cout;
             skips.push_back({x, cur, h, w});
         }
@@ -716,6 +734,7 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
             op_conv(u, op_as16(u, x, (size_t)B * h * w * cur), Lv.sw, Lv.sb, nullptr, 0, nullptr, B, h, w, cur, cur, 2, 0, o, false, true);
             u->top = m0;
             x = o; h = ho; w = wo;
+            u->tap(x, B * h * w, cur);
             skips.push_back({x, cur, h, w});
         }
     }
@@ -746,10 +765,13 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
     {
         void *o1 = u->allocS((size_t)B * h * w * cur);
         run_resnet(u, f, u->mid.res[0], x, h, w, o1);
+        u->tap(o1, B * h * w, cur);
         void *o2 = u->allocS((size_t)B * h * w * cur);
         run_transformer(u, f, u->mid.tr[0], o1, h, w, o2);
+        u->tap(o2, B * h * w, cur);
         void *o3 = u->allocS((size_t)B * h * w * cur);
         run_resnet(u, f, u->mid.res[1], o2, h, w, o3);
+        u->tap(o3, B * h * w, cur);
         x = o3;
     }
     if (u->is_controlnet) {
@@ -778,8 +800,10 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
             if (Lv.has_attn) {
                 void *t = u->allocS((size_t)B * h * w * cout);
                 run_resnet(u, f, Lv.res[j], cat, h, w, t);
+                u->tap(t, B * h * w, cout);
                 run_transformer(u, f, Lv.tr[j], t, h, w, o);
             } else run_resnet(u, f, Lv.res[j], cat, h, w, o);
+            u->tap(o, B * h * w, cout);
             u->top = mark;
             x = o; cur = cout;
         }
@@ -789,6 +813,7 @@ static int unet_run(ctx_unet *u, const float *sample, const float *timestep, con
             op_conv(u, op_as16(u, x, (size_t)B * h * w * cur), Lv.sw, Lv.sb, nullptr, 0, nullptr, B, h, w, cur, cur, 1, 1, o, false, true);
             u->top = m0;
             x = o; h *= 2; w *= 2;
+            u->tap(x, B * h * w, cur);
         }
     }
     f16 *y = u->allocH((size_t)B * h * w * cur);
@@ -927,6 +952,23 @@ extern "C" int32_t ctx_unet_set_residual_fp32(ctx_unet_t *u, int32_t on)
 {
     CTX_REQUIRE(u, "unet_set_residual_fp32: null handle");
     u->res32 = on != 0;
+    return CTX_OK;
+}
+
+/* Measurement aid: buf (fp16 device memory of `capacity` elements, or NULL to switch off) receives a copy of every block's output
+   of the following forwards, in execution order (conv_in; per level resnet, transformer, sampler; mid; up path).  After a forward,
+   ctx_unet_tap_count / ctx_unet_tap_info describe what was (or would have been: offsets past the capacity are not written) copied. */
+extern "C" int32_t ctx_unet_set_taps(ctx_unet_t *u, void *buf, int64_t capacity)
+{
+    CTX_REQUIRE(u && capacity >= 0, "unet_set_taps: bad args");
+    u->tap_buf = (f16 *)buf; u->tap_cap = buf ? (size_t)capacity : 0;
+    return CTX_OK;
+}
+extern "C" int32_t ctx_unet_tap_count(const ctx_unet_t *u) { return u ? (int32_t)u->taps.size() : -1; }
+extern "C" int32_t ctx_unet_tap_info(const ctx_unet_t *u, int32_t i, int64_t *offset, int32_t *rows, int32_t *channels)
+{
+    CTX_REQUIRE(u && offset && rows && channels && i >= 0 && i < (int32_t)u->taps.size(), "unet_tap_info: bad args");
+    *offset = (int64_t)u->taps[i].off; *rows = u->taps[i].rows; *channels = u->taps[i].C;
     return CTX_OK;
 }
 

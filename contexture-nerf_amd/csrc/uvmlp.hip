@@ -45,6 +45,7 @@ struct UvmPlan {
     int64_t out_w_off, out_b_off;
     UvmLayer layer[UVM_MAX_LAYERS];
     int64_t wt_off[UVM_MAX_LAYERS];   // layer i >= 1: W_i[:, hidden part]^T packed as an MFMA B operand (backward chain)
+    int64_t w16_off[UVM_MAX_LAYERS];  // layer i: the same weights as two fp16 planes (hi, lo x 2^11) in 32x32x16 B-fragment order, or -1
 };
 
 static int uvm_build_plan(int D, int W, int input_ch, int output_ch, int skip, UvmPlan &p, int64_t &total)
@@ -65,6 +66,11 @@ static int uvm_build_plan(int D, int W, int input_ch, int output_ch, int skip, U
     p.out_b_off = off; off += 4;
     p.wt_off[0] = -1;
     for (int i = 1; i < D; ++i) { p.wt_off[i] = off; off += (int64_t)W * W; }
+    // split-fp16 copies for the fast forward (k_uvmlp_fwd16): kp x W elements x (2 + 2) bytes = kp x W floats of space
+    for (int i = 0; i < D; ++i) {
+        if (W == 256 && EP == UVM_EPAD && p.layer[i].kp % 16 == 0) { p.w16_off[i] = off; off += (int64_t)p.layer[i].kp * W; }
+        else p.w16_off[i] = -1;
+    }
     total = off;
     return 0;
 }
@@ -118,6 +124,29 @@ __global__ void k_uvm_pack_t(const float *__restrict__ w, int W, int kin, int of
     dw[idx] = w[(int64_t)n * kin + off + k];
 }
 
+// fp16 split of the layer weights for k_uvmlp_fwd16: w = hi + lo * 2^-11 with hi = rn16(w), lo = rn16((w - hi) * 2^11): 22 bits of
+// mantissa in two fp16 planes.  Block (kb, nb) = hi[64 lanes][8] then lo[64 lanes][8]; lane (r, h) element j = w[nb*32 + r][map(kb*16 + 8h + j)]
+// — the B fragment of v_mfma_f32_32x32x16_f16, one 16-byte load per lane and plane.
+__global__ void k_uvm_pack16(const float *__restrict__ w, int W, int kin, int kp, int in_ch, int epad, int mode, f16 *__restrict__ dw)
+{
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)kp * W) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    const int64_t blk = idx >> 9;
+    const int nb = blk % (W / 32), kb = blk / (W / 32);
+    const int r = lane & 31, h = lane >> 5;
+    const int k = kb * 16 + 8 * h + j, n = nb * 32 + r;
+    int src_k;
+    if (mode == 2) src_k = k;
+    else if (mode == 0) src_k = k < in_ch ? k : -1;
+    else src_k = k < in_ch ? k : (k < epad ? -1 : k - epad + in_ch);
+    const float v = (src_k >= 0 && src_k < kin) ? w[(int64_t)n * kin + src_k] : 0.0f;
+    const f16 hi = (f16)v;
+    const f16 lo = (f16)((v - (float)hi) * 2048.0f);
+    dw[blk * 1024 + lane * 8 + j] = hi;
+    dw[blk * 1024 + 512 + lane * 8 + j] = lo;
+}
+
 __global__ void k_uvm_pack_out(const float *__restrict__ w, const float *__restrict__ b, int W, int out_ch,
                                float *__restrict__ dw, float *__restrict__ db)
 {
@@ -144,6 +173,9 @@ extern "C" int32_t ctx_uvmlp_pack(const float *const *ws, const float *const *bs
         if (i >= 1)
             hipLaunchKernelGGL(k_uvm_pack_t, dim3((unsigned)cdiv64((int64_t)W * W, 256)), dim3(256), 0, s, ws[i], W, kin,
                                i == skip + 1 ? input_ch : 0, dst + p.wt_off[i]);
+        if (p.w16_off[i] >= 0)
+            hipLaunchKernelGGL(k_uvm_pack16, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, ws[i], W, kin, p.layer[i].kp, input_ch, p.epad, mode,
+                               (f16 *)(dst + p.w16_off[i]));
     }
     hipLaunchKernelGGL(k_uvm_pack_out, dim3(cdiv(output_ch * W, 256)), dim3(256), 0, s, ws[D], bs[D], W, output_ch,
                        dst + p.out_w_off, dst + p.out_b_off);
@@ -316,6 +348,199 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
     }
 }
 
+
+// =====================================================================================================================
+// Fast forward of the 2-D texture field (W = 256): the same network on the 16-bit matrix pipe with SPLIT operands.
+// Every activation and weight is carried as two fp16 numbers, x = hi + lo * 2^-11 (hi = rn16(x), lo = rn16((x - hi) * 2^11)): 22 bits
+// of mantissa, i.e. fp32-grade operands.  A product a.w = ah.wh + 2^-11 (ah.wl + al.wh) + 2^-22 al.wl: the first three terms are three
+// v_mfma_f32_32x32x16_f16 passes into TWO fp32 accumulator sets (main, cross), the last (relative 2^-22) is dropped.  Per 16-deep k-step
+// that is 3 x 32 cycles against 8 x 64 for v_mfma_f32_32x32x2_f32: 5.3x the matrix rate at the f32 path's accuracy (measured against
+// the reference's vectors at the same tolerances; CTX_UVMLP_EXACT_F32=1 selects the exact-f32 kernel).
+// One workgroup = 128 texels, 4 waves; wave w owns hidden columns [64w, 64w+64) as 4 x 2 accumulator tiles of 32 x 32 (x 2 sets), one
+// wave per SIMD, so a weight fragment fetched from L2 serves 128 texels.  Activations live in LDS as two fp16 planes [128][312].
+// `saved` gets what k_uvmlp_fwd leaves (embedding, post-ReLU activations as hi + lo * 2^-11, ReLU bit masks per 64-texel tile).
+#define UVM16_TM 128
+#define UVM16_LO 312              // halves: a row's lo plane sits this far behind its hi plane (48 + 256 + 8)
+#define UVM16_STRIDE 632          // halves per row PAIR (hi | lo): 1264 bytes = 16 x odd -> conflict-free ds_read_b128 over 16 rows, and
+                                  // the lo plane within the 16-bit immediate offset of every DS access to the hi plane
+__global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ uv, const float *__restrict__ emb, int64_t N, int res, int L,
+                                                     const float *__restrict__ packed, UvmPlan plan,
+                                                     float *__restrict__ raw, float *__restrict__ tex, float *__restrict__ saved)
+{
+    constexpr int W = 256, EP = UVM_EPAD, STRIDE = UVM16_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) f16 pl[];      // [128 rows][hi 312 | lo 312 | pad 8] halves
+    f16 *phi = pl, *plo = pl + UVM16_LO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t n0 = (int64_t)blockIdx.x * UVM16_TM;
+    auto put = [&](int row, int col, float v) {
+        const f16 hi = (f16)v;
+        phi[row * STRIDE + col] = hi;
+        plo[row * STRIDE + col] = (f16)((v - (float)hi) * 2048.0f);
+    };
+    auto get = [&](int row, int col) { return (float)phi[row * STRIDE + col] + (float)plo[row * STRIDE + col] * (1.0f / 2048.0f); };
+
+    // ---- Fourier embedding into columns [0,48): two threads per texel, 24 columns each -------------------------------
+    {
+        const int row = tid >> 1, half = tid & 1;
+        const int64_t n = n0 + row;
+        const int d = plan.dims;
+        float x0 = 0.f, x1 = 0.f;
+        if (n < N && !emb) {
+            if (uv) { x0 = uv[n * d + 0]; x1 = uv[n * d + 1]; }
+            else {
+                int i = (int)(n / res), j = (int)(n % res);
+                float step = 1.0f / (float)(res - 1);
+                x0 = (j < res / 2) ? (float)j * step : 1.0f - (float)(res - 1 - j) * step;
+                x1 = (i < res / 2) ? (float)i * step : 1.0f - (float)(res - 1 - i) * step;
+            }
+        }
+        for (int e = half * (EP / 2); e < (half + 1) * (EP / 2); ++e) {
+            float val = 0.f;
+            if (emb) val = (e < plan.in_ch && n < N) ? emb[n * plan.in_ch + e] : 0.f;
+            else if (e < d) val = e == 0 ? x0 : x1;
+            else if (e < d * (1 + 2 * L)) {
+                int l = (e - d) / (2 * d), q = (e - d) % (2 * d);
+                float a = ((q % d) == 0 ? x0 : x1) * (float)(1 << l);
+                val = (q >= d) ? cosf(a) : sinf(a);
+            }
+            put(row, e, val);
+        }
+    }
+    __syncthreads();
+    if (saved) {
+        for (int i = tid; i < UVM16_TM * EP; i += 256) {
+            int row = i / EP, c = i % EP;
+            if (n0 + row < N) saved[(n0 + row) * EP + c] = get(row, c);
+        }
+    }
+
+    for (int li = 0; li < plan.n_hidden; ++li) {
+        const UvmLayer ly = plan.layer[li];
+        const int nkb = ly.kp / 16;
+        const f16 *ah_base = phi + r * STRIDE + ly.col0 + 8 * h;
+        const f16 *al_base = plo + r * STRIDE + ly.col0 + 8 * h;
+        const float *bias = packed + ly.b_off;
+        unsigned long long bits0 = 0, bits1 = 0;   // ReLU patterns of the two 64-texel tiles, in k_uvmlp_fwd's bit layout
+        uint32_t outv[2][4][16];                   // this layer's outputs (hi | lo << 16) wait in registers until every wave has read its inputs
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {           // the wave's two 32-column blocks one after the other: 128 accumulator registers
+            f32x16 acc[4], acx[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { acc[a][q] = 0.f; acx[a][q] = 0.f; }
+            // weight fragments: block (kb, nbg) at ((kb * 8 + nbg) * 1024) halves, hi[64][8] then lo[64][8]
+            const f16 *wbase = (const f16 *)(packed + plan.w16_off[li]) + (size_t)(wave * 2 + nb) * 1024 + lane * 8;
+            f16x8 b0h, b0l, b1h, b1l, b2h, b2l;    // k-steps kb, kb+1, kb+2: two steps of prefetch (one wave per SIMD hides nothing)
+            auto load_b = [&](int kb, f16x8 &xh, f16x8 &xl) {
+                const f16 *p = wbase + (size_t)uvm_opaque(kb < nkb ? kb : nkb - 1) * 8 * 1024;
+                xh = *(const f16x8 *)(p); xl = *(const f16x8 *)(p + 512);
+            };
+            load_b(0, b0h, b0l); load_b(1, b1h, b1l);
+            f16x8 ah[4], al[4], nah[4], nal[4];
+            auto load_a = [&](int kb, f16x8 (&xh)[4], f16x8 (&xl)[4]) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    xh[mb] = *(const f16x8 *)(ah_base + mb * 32 * STRIDE + kb * 16);
+                    xl[mb] = *(const f16x8 *)(al_base + mb * 32 * STRIDE + kb * 16);
+                }
+            };
+            load_a(0, ah, al);
+            for (int kb = 0; kb < nkb; ++kb) {
+                // the next step's activation fragments (LDS) and the weights two steps ahead (L2) are requested before this step's
+                // MFMAs issue: with one wave per SIMD nothing else covers their latency
+                load_b(kb + 2, b2h, b2l);
+                load_a(kb + 1 < nkb ? kb + 1 : kb, nah, nal);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], b0h, acc[mb], 0, 0, 0);
+                    acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], b0l, acx[mb], 0, 0, 0);
+                    acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], b0h, acx[mb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                b0h = b1h; b0l = b1l; b1h = b2h; b1l = b2l;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) { ah[mb] = nah[mb]; al[mb] = nal[mb]; }
+            }
+            const float bv = bias[wave * 64 + nb * 32 + r];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float v = acc[mb][q] + acx[mb][q] * (1.0f / 2048.0f) + bv;
+                    const unsigned long long on = (unsigned long long)(v > 0.f) << ((nb * 2 + (mb & 1)) * 16 + q);
+                    if (mb < 2) bits0 |= on; else bits1 |= on;
+                    const float y = v > 0.f ? v : 0.f;
+                    const f16 yh = (f16)y;
+                    const f16 yl = (f16)((y - (float)yh) * 2048.0f);
+                    outv[nb][mb][q] = (uint32_t)__builtin_bit_cast(unsigned short, yh) | ((uint32_t)__builtin_bit_cast(unsigned short, yl) << 16);
+                }
+        }
+        __syncthreads();                       // everyone has finished reading this layer's input
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = wave * 64 + nb * 32 + r;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int o = (mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * STRIDE + EP + col;
+                    ((unsigned short *)phi)[o] = (unsigned short)(outv[nb][mb][q] & 0xffffu);
+                    ((unsigned short *)plo)[o] = (unsigned short)(outv[nb][mb][q] >> 16);
+                }
+        }
+        if (saved) {
+            unsigned long long *mk = (unsigned long long *)(saved + N * (int64_t)(EP + plan.n_hidden * W));
+            const int64_t nt64 = (N + UVM_TM - 1) / UVM_TM, t64 = (int64_t)blockIdx.x * 2;
+            mk[((int64_t)li * nt64 + t64) * W + tid] = bits0;
+            if (t64 + 1 < nt64) mk[((int64_t)li * nt64 + t64 + 1) * W + tid] = bits1;
+        }
+        __syncthreads();
+        if (saved) {   // post-ReLU activations [layer][texel][W] as the value the next layer consumes (hi + lo 2^-11)
+            float *dst = saved + N * EP + (int64_t)li * N * W;
+            for (int i = tid; i < UVM16_TM * (W / 4); i += 256) {
+                const int row = i / (W / 4), c4 = i % (W / 4);
+                if (n0 + row < N) {
+                    const f16x4 vh = *(const f16x4 *)(phi + row * STRIDE + EP + c4 * 4), vl = *(const f16x4 *)(plo + row * STRIDE + EP + c4 * 4);
+                    float4 o;
+                    o.x = (float)vh[0] + (float)vl[0] * (1.0f / 2048.0f); o.y = (float)vh[1] + (float)vl[1] * (1.0f / 2048.0f);
+                    o.z = (float)vh[2] + (float)vl[2] * (1.0f / 2048.0f); o.w = (float)vh[3] + (float)vl[3] * (1.0f / 2048.0f);
+                    *(float4 *)(dst + (n0 + row) * W + c4 * 4) = o;
+                }
+            }
+        }
+    }
+
+    // ---- output layer (256 -> out_ch <= 4) on the VALU, 2 threads per texel ------------------------------------------
+    {
+        const int row = tid >> 1, part = tid & 1;
+        const float *ow = packed + plan.out_w_off + part * 128;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 128; k += 8) {
+            const f16x8 vh = *(const f16x8 *)(phi + row * STRIDE + EP + part * 128 + k), vl = *(const f16x8 *)(plo + row * STRIDE + EP + part * 128 + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = (float)vh[j] + (float)vl[j] * (1.0f / 2048.0f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < plan.out_ch) s[c] += x * ow[c * W + k + j];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += __shfl_xor(s[c], 1, 64);
+        const int64_t n = n0 + row;
+        if (part == 0 && n < N) {
+            for (int c = 0; c < plan.out_ch; ++c) {
+                float v = s[c] + packed[plan.out_b_off + c];
+                raw[n * plan.out_ch + c] = v;
+                if (tex) tex[(int64_t)c * N + n] = (tanhf(v) + 1.0f) / 2.0f;
+            }
+        }
+    }
+}
+
 static inline int uvm_epad(int input_ch) { return input_ch <= UVM_EPAD ? UVM_EPAD : UVM_EPAD3; }
 
 extern "C" int64_t ctx_uvmlp_saved_bytes(int64_t N, int32_t D, int32_t W, int32_t input_ch)
@@ -342,6 +567,19 @@ extern "C" int32_t ctx_uvmlp_fwd_save(const float *uv, const float *emb, int64_t
     unsigned grid = (unsigned)cdiv64(N, UVM_TM);
     size_t lds = (size_t)UVM_TM * ((p.epad == UVM_EPAD ? UVM_EPAD : 0) + W + 4) * 4;   // the 3-D layout overlays the embedding
     const float *pk = (const float *)packed;
+    {
+        // the split-fp16 kernel for the reference's texture field (2-D, W = 256) unless the exact-f32 pipe is asked for
+        const char *ex = getenv("CTX_UVMLP_EXACT_F32");
+        bool fast = dims == 2 && W == 256 && p.epad == UVM_EPAD && !(ex && ex[0] == '1');
+        for (int i = 0; i < D && fast; ++i) fast = p.w16_off[i] >= 0;
+        if (fast) {
+            const size_t lds16 = (size_t)UVM16_TM * UVM16_STRIDE * sizeof(f16);
+            (void)hipFuncSetAttribute((const void *)k_uvmlp_fwd16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+            hipLaunchKernelGGL(k_uvmlp_fwd16, dim3((unsigned)cdiv64(N, UVM16_TM)), dim3(256), lds16, s, uv, emb, N, res, L, pk, p, raw, tex_chw, saved);
+            CTX_CHECK_LAUNCH("uvmlp_fwd16");
+            return CTX_OK;
+        }
+    }
 #define UVM_FWD(WW, EE)                                                                                                     \
     do {                                                                                                                    \
         (void)hipFuncSetAttribute((const void *)k_uvmlp_fwd<WW, EE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -162,16 +162,23 @@ class StableDiffusion:
         def done(self):
             return self.i >= len(self.timesteps)
 
-        def advance(self):
+        def model_input(self):
+            """-> (x [2,C+1,h,w] = the CFG pair of this view's latents with its depth, t)."""
             t = self.timesteps[self.i]
             latent_model_input = torch.cat([self.latents] * 2)
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
-            x = torch.cat([latent_model_input, self.depth2], dim=1)
-            noise_pred = self.unet(x, float(t), encoder_hidden_states=self.text_embeddings)['sample']
+            return torch.cat([latent_model_input, self.depth2], dim=1), t
+
+        def apply(self, noise_pred, t):
+            """noise_pred [2,C,h,w] = (uncond, text) of this view -> fused CFG + PLMS update."""
             if self.on_step is not None:
                 self.on_step(t, self.latents, self.noise)
             self.latents = self.scheduler.step_cfg(noise_pred, self.guidance_scale, int(t), self.latents)['prev_sample']
             self.i += 1
+
+        def advance(self):
+            x, t = self.model_input()
+            self.apply(self.unet(x, float(t), encoder_hidden_states=self.text_embeddings)['sample'], t)
 
     def _prepare(self, inputs, original_depth_mask, update_mask, latent_mode, image_size):
         depth_mask = F.interpolate(original_depth_mask, size=(image_size // 8, image_size // 8), mode='bicubic', align_corners=False)
@@ -267,6 +274,53 @@ class StableDiffusion:
                 jobs[k].latents.record_stream(main)
                 rgb = self.decode_latents(jobs[k].latents)
                 outs.append((rgb, jobs[k].latents) if metas[k] else (rgb, []))
+        return outs
+
+    def img2img_step_batched(self, calls, views_per_eval=6):
+        """Several img2img_step calls (views, possibly of different meshes) denoised in LOCKSTEP as ONE UNet evaluation of batch
+        2 x views_per_eval per step: rows [u_0, c_0, u_1, c_1, ...] (every view keeps its own text embeddings, depth, seed, scheduler
+        state and fused CFG / PLMS update).  At M = views x 2 x h x w rows every layer is a large GEMM (no split-K slabs, full tiles),
+        which one view at CFG batch 2 cannot offer.  Groups are ALWAYS evaluated at exactly views_per_eval views (a short last group
+        is padded with copies of its last view, whose results are dropped): the executor's plan depends on the row count only and
+        every row's arithmetic is independent of the other rows, so a view's result does not depend on which views share its batch
+        — the atlas of a mesh is the same bits whether it is painted alone or inside a mesh batch.  (It is NOT bit-identical to the
+        batch-2 loop of img2img_step: other tile / split-K plans sum in another order; same tolerance against the oracle.)
+        All calls must share image_size and num_inference_steps / strength (one timestep schedule); otherwise this falls back
+        to img2img_step_multi.  A single call is padded like any short group."""
+        n, G = len(calls), int(views_per_eval)
+        key = lambda kw: (kw.get('image_size', 512), kw.get('num_inference_steps', 50), kw.get('strength', 0.5), kw.get('latent_mode', False))
+        if n < 1 or G < 2 or 2 * G > 16 or any(key(kw) != key(calls[0]) for kw in calls) or any(kw.get('intermediate_vis') for kw in calls):
+            return self.img2img_step_multi(calls)
+        jobs, metas = [], []
+        with torch.no_grad():
+            for kw in calls:
+                image_size, latent_mode = kw.get('image_size', 512), kw.get('latent_mode', False)
+                latents, depth_mask, update_mask = self._prepare(kw['inputs'], kw['original_depth_mask'], kw.get('update_mask'),
+                                                                 latent_mode, image_size)
+                jobs.append(StableDiffusion._Denoise(self, self.unet, self._new_scheduler(), kw['text_embeddings'], latents, depth_mask,
+                                                     kw.get('strength', 0.5), kw.get('num_inference_steps', 50), update_mask,
+                                                     kw.get('fixed_seed'), kw.get('guidance_scale', 100)))
+                metas.append(latent_mode)
+            for g0 in range(0, n, G):
+                grp = jobs[g0:g0 + G]
+                pad = [grp[-1]] * (G - len(grp))                       # padded rows: same arithmetic, results dropped
+                ctx = torch.cat([j.text_embeddings for j in grp + pad])
+                steps = len(grp[0].timesteps)
+                if any(len(j.timesteps) != steps or not torch.equal(j.timesteps, grp[0].timesteps) for j in grp):
+                    raise L.CtxError("img2img_step_batched: the views of one evaluation must share their timestep schedule")
+                for _ in range(steps):
+                    xs, t = [], None
+                    for j in grp:
+                        x, t = j.model_input()
+                        xs.append(x)
+                    xs += [xs[-1]] * len(pad)
+                    noise = self.unet(torch.cat(xs), float(t), encoder_hidden_states=ctx)['sample']
+                    for v, j in enumerate(grp):
+                        j.apply(noise[2 * v:2 * v + 2], t)
+            outs = []
+            for j, lm in zip(jobs, metas):
+                rgb = self.decode_latents(j.latents)
+                outs.append((rgb, j.latents) if lm else (rgb, []))
         return outs
 
     def img2img_step_pair(self, calls):

@@ -159,7 +159,11 @@ class ConTEXTure:
         """Several views painted with their denoise loops in flight together (StableDiffusion.img2img_step_multi): same result
         per view as paint_viewpoint.  Returns [(rgb_output, object_mask, last)] per view."""
         preps = [self._paint_prepare(d, image_size, num_inference_steps) for d in datas]
-        outs = self.diffusion.img2img_step_multi([p[0] for p in preps])
+        vpe = int(getattr(self.cfg.optim, 'views_per_eval', 0))
+        if vpe > 1 and hasattr(self.diffusion, 'img2img_step_batched'):
+            outs = self.diffusion.img2img_step_batched([p[0] for p in preps], views_per_eval=vpe)
+        else:
+            outs = self.diffusion.img2img_step_multi([p[0] for p in preps])
         res = []
         for (kw, ctx), (rgb, _) in zip(preps, outs):
             rgb_output, mask = self._paint_finish(ctx, rgb)
@@ -403,12 +407,14 @@ class ConTEXTure:
         masks = self.define_view_weights(mine)          # an idle rank (no views of this mesh) still joins the all-reduce(MAX)
         # a rank that owns several views keeps `views_in_flight` of them (default 3) in the denoise loop at once
         infl = max(1, int(getattr(self.cfg.optim, 'views_in_flight', 3)))
+        if int(getattr(self.cfg.optim, 'views_per_eval', 0)) > 1:
+            infl = int(self.cfg.optim.views_per_eval)                # one lockstep evaluation per group of that many views
         if not hasattr(self.diffusion, 'img2img_step_multi'):
             infl = 1
         j = 0
         while j < len(mine):
             grp = mine[j:j + infl]
-            if len(grp) > 1:
+            if len(grp) > 1 or int(getattr(self.cfg.optim, 'views_per_eval', 0)) > 1:
                 res = self.paint_viewpoints_multi([self.train_views[k] for k in grp], image_size=image_size,
                                                   num_inference_steps=num_inference_steps)
                 for o, (rgb, obj_mask, last) in enumerate(res):

@@ -240,6 +240,13 @@ int32_t ctx_unet_set_residuals(ctx_unet_t *u, const void *residuals /*nullable*/
    passes).  The workspace grows: query ctx_unet_workspace_bytes again after switching. */
 int32_t ctx_unet_set_residual_fp32(ctx_unet_t *u, int32_t on);
 int32_t ctx_unet_stats(const ctx_unet_t *u, int32_t klass, int64_t *launches, double *flops);
+/* Measurement aid (tools/precision_attribution.py; no reference counterpart): buf (fp16 device memory of `capacity` elements, NULL =
+   off) receives a copy of every block's output (fp16 NHWC [rows, channels]) of the following plain forwards, in execution order:
+   conv_in; per down level resnet (, transformer) x layers, downsampler; mid resnet, transformer, resnet; per up level resnet
+   (, transformer) x (layers + 1), upsampler.  ctx_unet_tap_count / ctx_unet_tap_info describe the last forward's taps. */
+int32_t ctx_unet_set_taps(ctx_unet_t *u, void *buf, int64_t capacity);
+int32_t ctx_unet_tap_count(const ctx_unet_t *u);
+int32_t ctx_unet_tap_info(const ctx_unet_t *u, int32_t i, int64_t *offset, int32_t *rows, int32_t *channels);
 
 /* ---- VAE decoder (src/stable_diffusion_depth.py:976-990 decode_latents -> diffusers AutoencoderKL.decode) ---------- */
 typedef struct ctx_vae ctx_vae_t;

@@ -375,37 +375,96 @@ def _h(x):
     return x.half().float()
 
 
-def forward_fp16_storage(model, sample, timestep, ctx, q=_h, q_res=_h, q_w=_h):
-    def res_fwd(m, x, temb):
+class _PermLinear:
+    """y = x W^T + b with the K sum taken in `chunks` pieces added in REVERSE order: the same real-number result through a
+    different fp32 accumulation order (the "two correct implementations" experiment of tests / tools)."""
+
+    def __init__(self, chunks=4):
+        self.chunks = chunks
+
+    def linear(self, m, x):
+        K = x.shape[-1]
+        step = -(-K // self.chunks)
+        acc = None
+        for k0 in reversed(range(0, K, step)):
+            part = x[..., k0:k0 + step] @ m.weight[:, k0:k0 + step].T
+            acc = part if acc is None else acc + part
+        return acc if m.bias is None else acc + m.bias
+
+    def conv(self, m, x):
+        C = x.shape[1]
+        step = -(-C // self.chunks)
+        acc = None
+        for c0 in reversed(range(0, C, step)):
+            part = F.conv2d(x[:, c0:c0 + step], m.weight[:, c0:c0 + step], None, m.stride, m.padding)
+            acc = part if acc is None else acc + part
+        return acc if m.bias is None else acc + m.bias[None, :, None, None]
+
+
+def forward_fp16_storage(model, sample, timestep, ctx, q=_h, q_res=_h, q_w=_h, taps=None, p16=False, temb16=False, autocast=False,
+                         perm=None):
+    """The precision contract restated (see above).  Knobs, all off by default (= one rounding per FUSED operation, which is what
+    a fused implementation stores):
+      p16      softmax probabilities rounded to fp16 before the P V product (flash / SDPA kernels do);
+      temb16   SiLU(temb) and each ResBlock's time_emb_proj output rounded (they are fp16 tensors under autocast);
+      autocast EVERY op-level rounding torch.autocast would make in diffusers' eager graph: each conv / linear output, each
+               residual / bias-free add, GEGLU's two halves, gelu(gate) and their product, proj_out before the skip add;
+               implies p16 and temb16.  This is the reference's literal contract (src/stable_diffusion_depth.py:330);
+      perm     a _PermLinear: every matmul / conv accumulates its K sum in another order (identical real-number result).
+    taps: a list that receives every block's output (NCHW), in the engine's tap order."""
+    p16, temb16 = p16 or autocast, temb16 or autocast
+    qa = q if autocast else (lambda v: v)                       # op-level roundings that a fused kernel does not make
+
+    def lin(m, x):
+        return perm.linear(m, x) if perm is not None else m(x)
+
+    def cv(m, x):
+        return perm.conv(m, x) if perm is not None else m(x)
+
+    def tap(x):
+        if taps is not None:
+            taps.append(x)
+        return x
+
+    def res_fwd(m, x, temb_act):
         t = q(F.silu(m.norm1(x)))
-        hh = q(m.conv1(t) + m.time_emb_proj(F.silu(temb))[:, :, None, None])
+        tp = lin(m.time_emb_proj, temb_act)
+        tp = q(tp) if temb16 else tp
+        hh = q(qa(cv(m.conv1, t)) + tp[:, :, None, None])
         t2 = q(F.silu(m.norm2(hh)))
-        sc = x if m.conv_shortcut is None else m.conv_shortcut(q(x))
-        return q_res(sc + m.conv2(t2))
+        sc = x if m.conv_shortcut is None else qa(cv(m.conv_shortcut, q(x)))
+        return q_res(sc + qa(cv(m.conv2, t2)))
 
     def attn_fwd(m, x, c=None):
         c = x if c is None else c
         B, S, C = x.shape
         H = m.heads
-        qq = q(m.to_q(x)).view(B, S, H, C // H).transpose(1, 2)
-        k = q(m.to_k(c)).view(B, -1, H, C // H).transpose(1, 2)
-        v = q(m.to_v(c)).view(B, -1, H, C // H).transpose(1, 2)
-        a = torch.softmax((qq @ k.transpose(-1, -2)) * (C // H) ** -0.5, -1) @ v
-        return m.to_out[0](q(a.transpose(1, 2).reshape(B, S, C)))
+        qq = q(lin(m.to_q, x)).view(B, S, H, C // H).transpose(1, 2)
+        k = q(lin(m.to_k, c)).view(B, -1, H, C // H).transpose(1, 2)
+        v = q(lin(m.to_v, c)).view(B, -1, H, C // H).transpose(1, 2)
+        sc = (qq @ k.transpose(-1, -2)) * (C // H) ** -0.5
+        if p16:
+            # a flash kernel rounds the UNNORMALISED probabilities exp(s - max) to fp16 for the P V product and divides by the
+            # fp32 row sum afterwards
+            e = torch.exp(sc - sc.amax(-1, keepdim=True))
+            a = (q(e) @ v) / e.sum(-1, keepdim=True)
+        else:
+            a = torch.softmax(sc, -1) @ v
+        return qa(lin(m.to_out[0], q(a.transpose(1, 2).reshape(B, S, C))))
 
     def blk_fwd(m, x, c):
         x = q_res(x + attn_fwd(m.attn1, q(m.norm1(x))))
         x = q_res(x + attn_fwd(m.attn2, q(m.norm2(x)), q(c)))
-        a, g = m.ff.net[0].proj(q(m.norm3(x))).chunk(2, -1)
-        return q_res(x + m.ff.net[2](q(a * F.gelu(g))))
+        a, g = qa(lin(m.ff.net[0].proj, q(m.norm3(x)))).chunk(2, -1)
+        return q_res(x + qa(lin(m.ff.net[2], q(a * qa(F.gelu(g))))))
 
     def tr_fwd(m, x, c):
         B, C, H, W = x.shape
         hh = q(m.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
-        hh = q_res(m.proj_in(hh))
+        hh = q_res(lin(m.proj_in, hh))
         for b in m.transformer_blocks:
             hh = blk_fwd(b, hh, c)
-        hh = m.proj_out(q(hh)).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        hh = qa(lin(m.proj_out, q(hh))).reshape(B, H, W, C).permute(0, 3, 1, 2)
         return q_res(hh + x)
 
     import copy
@@ -415,29 +474,39 @@ def forward_fp16_storage(model, sample, timestep, ctx, q=_h, q_res=_h, q_w=_h):
             p.copy_(q_w(p))
         tt = torch.as_tensor(timestep).reshape(-1).expand(sample.shape[0])
         te = q(timestep_embedding(tt, mq.cfg['block_out_channels'][0]))
-        temb = q(mq.time_embedding.linear_2(q(F.silu(mq.time_embedding.linear_1(te)))))
-        hh = q_res(mq.conv_in(q(sample)))
+        temb = q(lin(mq.time_embedding.linear_2, q(F.silu(lin(mq.time_embedding.linear_1, te)))))
+        temb = F.silu(temb)
+        temb = q(temb) if temb16 else temb
+        hh = tap(q_res(cv(mq.conv_in, q(sample))))
         skips = [hh]
         for blk in mq.down_blocks:
             for j, r in enumerate(blk.resnets):
-                hh = res_fwd(r, hh, temb)
+                hh = tap(res_fwd(r, hh, temb))
                 if hasattr(blk, 'attentions'):
-                    hh = tr_fwd(blk.attentions[j], hh, ctx)
+                    hh = tap(tr_fwd(blk.attentions[j], hh, ctx))
                 skips.append(hh)
             if hasattr(blk, 'downsamplers'):
-                hh = q_res(blk.downsamplers[0](q(hh)))
+                hh = tap(q_res(cv(blk.downsamplers[0].conv, q(hh))))
                 skips.append(hh)
-        hh = res_fwd(mq.mid_block.resnets[0], hh, temb)
-        hh = tr_fwd(mq.mid_block.attentions[0], hh, ctx)
-        hh = res_fwd(mq.mid_block.resnets[1], hh, temb)
+        hh = tap(res_fwd(mq.mid_block.resnets[0], hh, temb))
+        hh = tap(tr_fwd(mq.mid_block.attentions[0], hh, ctx))
+        hh = tap(res_fwd(mq.mid_block.resnets[1], hh, temb))
         for blk in mq.up_blocks:
             for j, r in enumerate(blk.resnets):
-                hh = res_fwd(r, torch.cat([hh, skips.pop()], 1), temb)
+                hh = tap(res_fwd(r, torch.cat([hh, skips.pop()], 1), temb))
                 if hasattr(blk, 'attentions'):
-                    hh = tr_fwd(blk.attentions[j], hh, ctx)
+                    hh = tap(tr_fwd(blk.attentions[j], hh, ctx))
             if hasattr(blk, 'upsamplers'):
-                hh = q_res(blk.upsamplers[0](q(hh)))
-        return {'sample': mq.conv_out(q(F.silu(mq.conv_norm_out(hh))))}
+                hh = tap(q_res(cv(blk.upsamplers[0].conv, F.interpolate(q(hh), scale_factor=2.0, mode='nearest'))))
+        return {'sample': cv(mq.conv_out, q(F.silu(mq.conv_norm_out(hh))))}
+
+
+def forward_taps(model, sample, timestep, ctx):
+    """The fp32 forward with every block's output collected in the engine's tap order -> (out, [taps])."""
+    taps = []
+    ident = lambda v: v
+    out = forward_fp16_storage(model, sample, timestep, ctx, q=ident, q_res=ident, q_w=ident, taps=taps)
+    return out, taps
 
 
 def ref_only_forward(model, sample, timestep, ctx, noisy_cond_lat, is_cfg_guidance, down_res=None, mid_res=None):

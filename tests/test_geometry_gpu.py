@@ -381,6 +381,53 @@ def _field_bwd_abi(net, uv, c_raw, res=0, c_tex=None):
     return gws, gbs, saved[N * ep:N * ep + D * N * W].reshape(D, N, W)     # (the ReLU bit masks follow)
 
 
+def test_texture_field_split_fp16_vs_exact_f32(dev, golden):
+    """The default forward of the 2-D texture field (k_uvmlp_fwd16: fp16 hi + lo split operands, three MFMA passes, fp32 accumulate)
+    against the exact-f32 kernel behind CTX_UVMLP_EXACT_F32=1 and against the REFERENCE's stored outputs at the f32 path's own
+    tolerance; ragged N (not a multiple of the 128-texel tile), the training forward's saved tensors, and the backward through
+    either forward."""
+    import os
+    from contexture_nerf_amd import run_nerf_helpers as rnh
+    torch.manual_seed(1234)
+    net = rnh.NeRF2D(D=8, W=256, input_ch=42, output_ch=3, skips=[4]).to(dev)
+    e = torch.tensor(golden['embed_y'], device=dev)
+    y_fast = net(e)
+    np.testing.assert_allclose(y_fast.detach().cpu().numpy(), golden['nerf2d_seed1234_y'], rtol=1e-4, atol=2e-5)     # the reference's own forward
+    os.environ["CTX_UVMLP_EXACT_F32"] = "1"
+    try:
+        y_exact = net(e)
+    finally:
+        os.environ.pop("CTX_UVMLP_EXACT_F32")
+    d = float((y_fast - y_exact).abs().max() / y_exact.abs().max())
+    assert d < 2e-6, d                                              # 22-bit split operands: fp32-grade
+    assert not torch.equal(y_fast, y_exact)                         # ... and really another kernel
+    for N in (1, 127, 129, 1000, 66000):
+        g = torch.Generator().manual_seed(N)
+        uv = torch.rand(N, 2, generator=g).to(dev)
+        with torch.no_grad():
+            a = net.forward_uv(uv) if hasattr(net, 'forward_uv') else net(rnh.get_embedder(10)[0](uv))
+            os.environ["CTX_UVMLP_EXACT_F32"] = "1"
+            try:
+                b = net.forward_uv(uv) if hasattr(net, 'forward_uv') else net(rnh.get_embedder(10)[0](uv))
+            finally:
+                os.environ.pop("CTX_UVMLP_EXACT_F32")
+        assert a.shape == b.shape and float((a - b).abs().max()) < 3e-6 * max(1.0, float(b.abs().max())), N
+    # training forward + backward: parameter gradients through the fast forward's saved tensors == through the exact one's
+    grads = []
+    for exact in (False, True):
+        if exact:
+            os.environ["CTX_UVMLP_EXACT_F32"] = "1"
+        try:
+            net.zero_grad(set_to_none=True)
+            tex, raw = net.texture_map(64)
+            (tex * torch.linspace(-1, 1, tex.numel(), device=dev).reshape(tex.shape)).sum().backward()
+            grads.append([p.grad.clone() for p in net.parameters()])
+        finally:
+            os.environ.pop("CTX_UVMLP_EXACT_F32", None)
+    for ga, gb in zip(*grads):
+        assert float((ga - gb).abs().max()) <= 2e-5 * max(float(gb.abs().max()), 1e-6)
+
+
 @pytest.mark.parametrize("W,N", [(64, 1), (128, 517), (256, 4133), (256, 64 * 300), (256, 64 * 700 + 5)])
 def test_texture_field_backward_vs_oracle(dev, W, N):
     """ragged texel counts (tile tails, fewer texel ranges than workgroups, more tiles than persistent workgroups), the

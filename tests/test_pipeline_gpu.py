@@ -21,10 +21,11 @@ def _tiny_sd(dev, seed=0):
     return StableDiffusion(dev, unet=net), ref, cfg
 
 
-@pytest.mark.parametrize("steps", [2, 6])
+@pytest.mark.parametrize("steps", [2, 6, 50])
 def test_img2img_denoised_latents_vs_oracle(dev, steps):
-    """Denoised latents after the full PLMS loop (steps+1 UNet evals, CFG 10) vs the fp32 oracle loop.
-    Tolerance: 5e-3 relative L2 (fp16 UNet error 1.4e-3 per eval, amplified by guidance 10 and chained steps)."""
+    """Denoised latents after the full PLMS loop (steps+1 UNet evals, CFG 10) vs the fp32 oracle loop; 50 steps = the chain
+    BASELINE quotes (51 evaluations, the error fed back through the 4-step PLMS history at guidance 10).
+    Gate: measured x 1.15 (fp16 UNet error 1.4e-3 per evaluation, amplified by guidance 10 and chained steps)."""
     from oracle.scheduler import PNDMRef, cfg as cfg_combine
     sd, ref, cfg = _tiny_sd(dev)
     g = torch.Generator().manual_seed(5)
@@ -60,7 +61,8 @@ def test_img2img_denoised_latents_vs_oracle(dev, steps):
                                   image_size=size)
     rel = np.linalg.norm(lat_p.cpu().numpy() - x) / np.linalg.norm(x)
     print(f"img2img {steps} steps: denoised-latent rel L2 vs fp32 oracle = {rel:.3e}")
-    assert rel < 3e-3, rel                                          # measured 1.6-2.2e-3 (two and six PLMS steps at CFG 10)
+    gate = {2: 2.6e-3, 6: 2.6e-3, 50: 1e-1}[steps]                  # measured 1.6-2.2e-3 (two and six PLMS steps at CFG 10)
+    assert rel < gate, rel
     assert rgb.shape == (1, 3, size, size) and torch.isfinite(rgb).all()
     assert torch.equal(rgb, rgb2)                                   # same seed => same result (deterministic kernels)
 
@@ -120,6 +122,38 @@ def test_trainer_view_weights_paint_and_atlas(dev, meshes):
         assert mm.faces.shape == tr.mesh_model.mesh.faces.shape and mm.uvs.shape[1] == 2
         raw = open(os.path.join(p, 'albedo.png'), 'rb').read()
         assert struct.unpack('>II', raw[16:24]) == (128, 128) and os.path.exists(os.path.join(p, 'mesh.mtl'))
+
+
+def test_img2img_step_batched_lockstep_views(dev):
+    """StableDiffusion.img2img_step_batched: V views denoised in lockstep as ONE UNet evaluation of batch 2V per step.
+    (a) A view's result does not depend on which other views share its batch, nor on its position in it, nor on padding: the
+        executor's plan depends on the row count only and rows are arithmetically independent  -> torch.equal.
+    (b) Against the batch-2 loop of img2img_step (other tile / split-K plans -> another summation order) the denoised latents agree
+        to the fp16 tolerance of the parity tests, not bit for bit."""
+    sd, _, cfg = _tiny_sd(dev)
+    g = torch.Generator().manual_seed(9)
+    calls = []
+    for v in range(4):
+        calls.append(dict(text_embeddings=torch.randn(2, 9, cfg['cross_attention_dim'], generator=g).to(dev),
+                          inputs=torch.rand(1, 3, 72, 72, generator=g).to(dev), original_depth_mask=torch.rand(1, 1, 72, 72, generator=g).to(dev),
+                          guidance_scale=10.0, strength=1.0, num_inference_steps=4, update_mask=torch.ones(1, 1, 72, 72, device=dev),
+                          latent_mode=False, fixed_seed=11 + v, image_size=128))
+    lat = lambda kw: dict(kw, latent_mode=True, inputs=torch.zeros(1, 4, 16, 16, device=dev))
+    a = sd.img2img_step_batched([lat(c) for c in calls[:3]], views_per_eval=3)
+    b = sd.img2img_step_batched([lat(calls[2]), lat(calls[0])], views_per_eval=3)             # other order, padded group
+    c = sd.img2img_step_batched([lat(calls[0])], views_per_eval=3)                            # a single view, padded twice
+    d = sd.img2img_step_batched([lat(c_) for c_ in calls], views_per_eval=3)                  # two groups: 3 + 1 (padded)
+    assert torch.equal(a[0][1], b[1][1]) and torch.equal(a[2][1], b[0][1]) and torch.equal(a[0][1], c[0][1])
+    assert all(torch.equal(a[k][1], d[k][1]) for k in range(3)) and torch.equal(a[0][0], c[0][0])
+    for k in range(4):
+        rgb1, lat1 = sd.img2img_step(calls[k]['text_embeddings'], torch.zeros(1, 4, 16, 16, device=dev), calls[k]['original_depth_mask'],
+                                     **{kk: vv for kk, vv in lat(calls[k]).items() if kk not in ('text_embeddings', 'inputs', 'original_depth_mask')})
+        rel = float((d[k][1] - lat1).norm() / lat1.norm())
+        assert rel < 4e-3 and torch.isfinite(d[k][0]).all(), (k, rel)
+    assert not torch.equal(d[0][1], d[1][1])
+    # image-mode calls return (rgb, []) like img2img_step
+    e = sd.img2img_step_batched(calls[:2], views_per_eval=2)
+    assert e[0][0].shape == (1, 3, 128, 128) and e[0][1] == []
 
 
 def test_mesh_batch_painter_configs3_on_the_hip_path(dev):

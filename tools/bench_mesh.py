@@ -16,6 +16,7 @@ ap.add_argument("--views", type=int, default=6)
 ap.add_argument("--image", type=int, default=768)
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--in-flight", type=int, default=3)
+ap.add_argument("--per-eval", type=int, default=6, help="also time the lockstep batched evaluation of this many views (0: skip)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = CFG.TrainConfig()
@@ -37,6 +38,16 @@ for infl in sorted({1, 2, a.in_flight}):
     torch.cuda.synchronize()
     res[infl] = time.perf_counter() - t
     assert torch.isfinite(atlas).all()
+batched = None
+if a.per_eval > 1:
+    cfg.optim.views_per_eval = a.per_eval
+    tr.paint(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    atlas_b, cov_b = tr.paint()
+    torch.cuda.synchronize()
+    batched = time.perf_counter() - t
+    assert torch.isfinite(atlas_b).all()
+    cfg.optim.views_per_eval = 0
 out = {"metric": "sec/mesh full texture", "mesh": a.mesh, "faces": int(tr.mesh_model.mesh.faces.shape[0]), "views": len(tr.train_views),
        "render_grid": cfg.render.train_grid_size, "image": a.image, "plms_steps": a.steps, "unet_evals_per_view": a.steps + 1,
        "sec_per_mesh_serial": round(res[1], 3), "data": "synthetic (random-init weights, seeded text embedding)",
@@ -44,4 +55,6 @@ out = {"metric": "sec/mesh full texture", "mesh": a.mesh, "faces": int(tr.mesh_m
 for k in sorted(res):
     if k != 1:
         out[f"sec_per_mesh_{k}_views_in_flight"] = round(res[k], 3)
+if batched is not None:
+    out[f"sec_per_mesh_{a.per_eval}_views_per_evaluation"] = round(batched, 3)
 print(json.dumps(out))
