@@ -61,7 +61,9 @@ def test_img2img_denoised_latents_vs_oracle(dev, steps):
                                   image_size=size)
     rel = np.linalg.norm(lat_p.cpu().numpy() - x) / np.linalg.norm(x)
     print(f"img2img {steps} steps: denoised-latent rel L2 vs fp32 oracle = {rel:.3e}")
-    gate = {2: 2.6e-3, 6: 2.6e-3, 50: 1e-1}[steps]                  # measured 1.6-2.2e-3 (two and six PLMS steps at CFG 10)
+    # measured x 1.15 — 2 steps: 1.6-2.35e-3 by box / plan table, 6 steps: 1.6-2.2e-3, 50 steps (51 evaluations, the chain BASELINE
+    # quotes): 9.2e-4 — the errors of successive evaluations are independent and the PLMS history averages them
+    gate = {2: 2.8e-3, 6: 2.6e-3, 50: 1.2e-3}[steps]
     assert rel < gate, rel
     assert rgb.shape == (1, 3, size, size) and torch.isfinite(rgb).all()
     assert torch.equal(rgb, rgb2)                                   # same seed => same result (deterministic kernels)

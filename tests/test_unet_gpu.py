@@ -415,7 +415,7 @@ def test_unet_vs_oracle(dev, cfgname, h, w, L):
         # 1.3-1.5e-3 from fp32 and fp16 WEIGHTS alone cost 0.84e-3: tests/test_precision_cpu.py).  north_star's "1e-3 rel"
         # is therefore below the noise floor of fp16-operand arithmetic on this network; the gates are the floor-relative
         # ones below ("UNet tolerance").
-        assert r16 < 1.6e-3, f"UNet {cfgname} t={t}: {r16:.3e} vs the fp16-storage restatement"
+        assert r16 < 1.6e-3, f"UNet {cfgname} t={t}: {r16:.3e} vs the fp16-storage restatement"      # measured 1.26-1.34e-3 x 1.15
         assert r32 < 1.25 * floor + 2e-4, f"UNet {cfgname} t={t}: {r32:.3e} vs fp32 exceeds the fp16-storage floor {floor:.3e}"
 
 
@@ -618,9 +618,15 @@ def test_new_entry_points_fail_loudly(dev):
 
 def test_unet_full_size_vs_oracle(dev):
     """BASELINE configs[1] at full size: the SD2-depth UNet (866 M parameters, seeded random init shared through the state_dict),
-    CFG batch 2, latent 96 x 96, 77 context tokens — engine (tuned plans, 256x256 kernel, split-K, fused GroupNorm...) vs the fp32
-    oracle on the host cores (~15 s).  Same gate as the small configurations: rel L2 <= 2.5e-3 (fp16-storage noise floor
-    1.3-1.5e-3, tests/test_precision_cpu.py)."""
+    CFG batch 2, latent 96 x 96, 77 context tokens — engine (tuned plans, 256x256 kernel, split-K, fused GroupNorm...) against
+      * the fp32 oracle,
+      * the fp16-storage restatement of the reference's autocast contract (oracle.unet_ref.forward_fp16_storage: the same rounding
+        points as the engine), and
+      * that restatement with every K sum taken in another order (perm): how far two CORRECT implementations of one contract are
+        from each other (tests/test_precision_cpu.py shows why: fp32-order noise flips fp16 roundings, the flips decorrelate).
+    Gates, self-calibrating: the engine may be no further from the contract than 1.25 x what the contract is from itself, and no
+    further from fp32 than 1.15 x what the contract is (measured: 1.18e-3 vs 1.12e-3; 1.39e-3 vs 1.36e-3;
+    profiles/r03_precision_attribution.json has the same comparison after every one of the 45 blocks)."""
     from contexture_nerf_amd.unet import UNet2DConditionModel
     from oracle import unet_ref
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
@@ -630,12 +636,18 @@ def test_unet_full_size_vs_oracle(dev):
     net.load_state_dict(ref.state_dict())
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 5, 96, 96, generator=g); ctx = torch.randn(2, 77, 1024, generator=g)
+    t = torch.tensor(501.0)
     with torch.no_grad():
-        want = ref(x, torch.tensor(501.0), ctx)['sample']
+        want = ref(x, t, ctx)['sample']
+    fused = unet_ref.forward_fp16_storage(ref, x, t, ctx)['sample']
+    perm = unet_ref.forward_fp16_storage(ref, x, t, ctx, perm=unet_ref._PermLinear(4))['sample']
     got = net(x.to(dev), 501.0, ctx.to(dev))['sample']
-    r = _rel(got, want)
-    print(f"full-size UNet (latent 96, batch 2): rel L2 vs fp32 = {r:.3e}")
-    assert torch.isfinite(got).all() and r < 2.5e-3, r
+    r32, r16, floor16, floor32 = _rel(got, want), _rel(got, fused), _rel(perm, fused), _rel(fused, want)
+    print(f"full-size UNet (latent 96, batch 2): engine vs fp32 {r32:.3e} | engine vs fp16 contract {r16:.3e} | contract vs itself in another "
+          f"summation order {floor16:.3e} | contract vs fp32 {floor32:.3e}")
+    assert torch.isfinite(got).all()
+    assert r16 < 1.25 * floor16, (r16, floor16)
+    assert r32 < 1.15 * floor32 and r32 < 1.6e-3, (r32, floor32)
 
 
 def test_zero123pp_full_size_vs_oracle(dev):
@@ -643,7 +655,7 @@ def test_zero123pp_full_size_vs_oracle(dev):
     CFG batch 2 on the 3x2 view grid latent [2,4,120,80], the noised 40x40 condition latent parked by the 'w' pass (1 600 reference
     tokens appended to the level-0 self-attention K/V of the conditional row; 400 / 100 at the deeper levels), depth ControlNet
     over the 960x640 grid with conditioning scale 2 and its 13 residuals injected into the 'r' pass — against the fp32 oracle's
-    restatement of src/zero123plus.py:127-298 on the host cores.  Gate as at the small sizes (2.5e-3; fp16 floor 1.3-1.5e-3)."""
+    restatement of src/zero123plus.py:127-298 on the host cores.  Gate: measured x 1.15 (the fp16 contract's own floor is 1.3-1.5e-3)."""
     from contexture_nerf_amd.unet import UNet2DConditionModel, ControlNetModel
     from oracle import unet_ref
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
@@ -674,7 +686,7 @@ def test_zero123pp_full_size_vs_oracle(dev):
         no_ref = net(x.to(dev), t, encoder_hidden_states=ctx.to(dev))['sample']
     print(f"full-size Zero123++ evaluation (latent 120x80, 1600 ref tokens, ControlNet): rel L2 vs fp32 = {r:.3e}; "
           f"without the reference tokens {_rel(no_ref, want):.3e}")
-    assert torch.isfinite(got).all() and r < 2.5e-3, r
+    assert torch.isfinite(got).all() and r < 1.7e-3, r                # measured 1.33e-3 (x 1.15 + box / plan-table spread)
     assert _rel(no_ref, want) > 4 * r
 
 
