@@ -447,23 +447,28 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
                 }
             };
             load_a(0, ah, al);
-            for (int kb = 0; kb < nkb; ++kb) {
-                // the next step's activation fragments (LDS) and the weights two steps ahead (L2) are requested before this step's
-                // MFMAs issue: with one wave per SIMD nothing else covers their latency
+            // One k-step: the next step's activation fragments (LDS) and the weights two steps ahead (L2) are requested before this
+            // step's MFMAs issue — with one wave per SIMD nothing else covers their latency.  The loop walks two steps per trip over
+            // the two activation register sets (no copies); only the three small weight sets rotate.
+            auto step = [&](int kb, f16x8 (&ch)[4], f16x8 (&cl)[4], f16x8 (&nh)[4], f16x8 (&nl)[4]) {
                 load_b(kb + 2, b2h, b2l);
-                load_a(kb + 1 < nkb ? kb + 1 : kb, nah, nal);
+                load_a(kb + 1 < nkb ? kb + 1 : kb, nh, nl);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], b0h, acc[mb], 0, 0, 0);
-                    acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], b0l, acx[mb], 0, 0, 0);
-                    acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], b0h, acx[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[mb], b0h, acc[mb], 0, 0, 0);
+                    acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[mb], b0l, acx[mb], 0, 0, 0);
+                    acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[mb], b0h, acx[mb], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 b0h = b1h; b0l = b1l; b1h = b2h; b1l = b2l;
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) { ah[mb] = nah[mb]; al[mb] = nal[mb]; }
+            };
+            int kb = 0;
+            for (; kb + 2 <= nkb; kb += 2) {
+                step(kb, ah, al, nah, nal);
+                step(kb + 1, nah, nal, ah, al);
             }
+            if (kb < nkb) step(kb, ah, al, nah, nal);       // K = 48 and 304 are an odd number of 16-deep steps
             const float bv = bias[wave * 64 + nb * 32 + r];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
