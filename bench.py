@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--mesh-path", default="shapes/nascar.obj")
     p.add_argument("--mesh-views", type=int, default=6)
     p.add_argument("--in-flight", type=int, default=3, help="views a rank keeps in its denoise loop at once (optim.views_in_flight)")
+    p.add_argument("--per-eval", type=int, default=6, help="mesh leg: views a rank denoises in lockstep as ONE UNet evaluation of batch 2 x this "
+                                                            "(optim.views_per_eval; 0 / 1: --in-flight streams of batch 2 instead)")
     return p.parse_args()
 
 
@@ -64,6 +66,7 @@ def make_painter(a, dev, unet):
     cfg.guide.sd_image_size = a.latent * 8
     cfg.guide.num_inference_steps = 50
     cfg.optim.views_in_flight = a.in_flight
+    cfg.optim.views_per_eval = a.per_eval if a.per_eval > 1 else 0
     sd = StableDiffusion(dev, unet=unet)
     tr = ConTEXTure(cfg, device=dev, diffusion=sd)
     tr.train_views = tr.train_views[1:1 + a.mesh_views]
@@ -190,7 +193,7 @@ def main():
                 "config": {"workload": f"BASELINE configs[2]/[1] shapes: {a.mesh_path}, {a.mesh_views} views (Zero123PlusDataset 1..{a.mesh_views}) "
                                        f"@1200^2 render, SD2-depth fp16 at latent {S}^2, 50 PLMS steps (51 UNet evals) per view, VAE decode, "
                                        "view weights + UV scatter, all-reduce(MAX) [F] + all-reduce(SUM) [4,1024,1024]; random-init weights",
-                           "views": a.mesh_views, "views_in_flight": a.in_flight, "parallelism": f"view-shard x{world}"},
+                           "views": a.mesh_views, "views_in_flight": a.in_flight, "views_per_eval": a.per_eval, "parallelism": f"view-shard x{world}"},
                 "atlas_coverage": round(cover, 4)}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -350,7 +353,7 @@ def main():
         }
         out["sec_per_mesh"] = round(mesh_s, 3) if mesh_s is not None else None
         out["sec_per_mesh_note"] = (f"{'MEASURED' if mesh_s is not None else 'NOT MEASURED (' + str(mesh_cover) + ')'}: one ConTEXTure.paint of {a.mesh_path}, {a.mesh_views} views over {world} rank(s), "
-                                    f"{a.in_flight} views in flight per rank, 1200^2 render, 51 UNet evals + VAE decode per view, "
+                                    (f"{a.per_eval} views per lockstep evaluation (batch {2 * a.per_eval})" if a.per_eval > 1 else f"{a.in_flight} views in flight") + " per rank, 1200^2 render, 51 UNet evals + VAE decode per view, "
                                     f"view weights, UV scatter, atlas merge; coverage {mesh_cover}")
         if two is not None:
             out["views_in_flight"] = two

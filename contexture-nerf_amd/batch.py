@@ -59,7 +59,7 @@ class MeshBatchPainter:
             for (m, v) in grp:
                 tr = self.trainers[m]
                 preps.append(tr._paint_prepare(tr.train_views[self.view_ids[v]], image_size, num_inference_steps))
-            if vpe > 1 and hasattr(diffusion, 'img2img_step_batched'):
+            if len(grp) > 1 and vpe > 1 and hasattr(diffusion, 'img2img_step_batched'):
                 outs = diffusion.img2img_step_batched([p[0] for p in preps], views_per_eval=vpe)
             elif len(grp) > 1:
                 outs = diffusion.img2img_step_multi([p[0] for p in preps])

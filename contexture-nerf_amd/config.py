@@ -69,8 +69,8 @@ class OptimConfig:
     alpha: float = -100
     # additions of this build (not in the reference's OptimConfig):
     views_in_flight: int = 3         # denoise loops a rank keeps in flight on one GPU (n HIP streams over one weight blob)
-    views_per_eval: int = 0          # > 1: the views a rank owns are denoised in lockstep as ONE UNet evaluation of batch 2 x views_per_eval
-                                     # (StableDiffusion.img2img_step_batched) instead of views_in_flight streams of batch 2
+    views_per_eval: int = 0          # > 1: full groups of that many views a rank owns are denoised in lockstep as ONE UNet evaluation of batch
+                                     # 2 x views_per_eval (StableDiffusion.img2img_step_batched); left-over views and 0 / 1: views_in_flight streams of batch 2
     sds_iterations: int = 0          # 0: the per-view paint loop (north_star).  > 0: the reference's live paint() = paint_zero123plus
                                      # with that many SDS iterations (the reference hard-codes 5000, src/training/trainer.py:662)
 

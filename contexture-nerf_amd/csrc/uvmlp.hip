@@ -359,11 +359,11 @@ __global__ __launch_bounds__(W) void k_uvmlp_fwd(const float *__restrict__ uv, c
 // One workgroup = 128 texels, 4 waves; wave w owns hidden columns [64w, 64w+64) as 4 x 2 accumulator tiles of 32 x 32 (x 2 sets), one
 // wave per SIMD, so a weight fragment fetched from L2 serves 128 texels.  Activations live in LDS as two fp16 planes [128][312].
 // `saved` gets what k_uvmlp_fwd leaves (embedding, post-ReLU activations as hi + lo * 2^-11, ReLU bit masks per 64-texel tile).
-#define UVM16_TM 128
+#define UVM16_TM 64
 #define UVM16_LO 312              // halves: a row's lo plane sits this far behind its hi plane (48 + 256 + 8)
 #define UVM16_STRIDE 632          // halves per row PAIR (hi | lo): 1264 bytes = 16 x odd -> conflict-free ds_read_b128 over 16 rows, and
                                   // the lo plane within the 16-bit immediate offset of every DS access to the hi plane
-__global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ uv, const float *__restrict__ emb, int64_t N, int res, int L,
+__global__ __launch_bounds__(256, 2) void k_uvmlp_fwd16(const float *__restrict__ uv, const float *__restrict__ emb, int64_t N, int res, int L,
                                                      const float *__restrict__ packed, UvmPlan plan,
                                                      float *__restrict__ raw, float *__restrict__ tex, float *__restrict__ saved)
 {
@@ -380,9 +380,9 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
     };
     auto get = [&](int row, int col) { return (float)phi[row * STRIDE + col] + (float)plo[row * STRIDE + col] * (1.0f / 2048.0f); };
 
-    // ---- Fourier embedding into columns [0,48): two threads per texel, 24 columns each -------------------------------
+    // ---- Fourier embedding into columns [0,48): four threads per texel, 12 columns each ------------------------------
     {
-        const int row = tid >> 1, half = tid & 1;
+        const int row = tid >> 2, half = tid & 3;
         const int64_t n = n0 + row;
         const int d = plan.dims;
         float x0 = 0.f, x1 = 0.f;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
                 x1 = (i < res / 2) ? (float)i * step : 1.0f - (float)(res - 1 - i) * step;
             }
         }
-        for (int e = half * (EP / 2); e < (half + 1) * (EP / 2); ++e) {
+        for (int e = half * (EP / 4); e < (half + 1) * (EP / 4); ++e) {
             float val = 0.f;
             if (emb) val = (e < plan.in_ch && n < N) ? emb[n * plan.in_ch + e] : 0.f;
             else if (e < d) val = e == 0 ? x0 : x1;
@@ -421,13 +421,13 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
         const f16 *ah_base = phi + r * STRIDE + ly.col0 + 8 * h;
         const f16 *al_base = plo + r * STRIDE + ly.col0 + 8 * h;
         const float *bias = packed + ly.b_off;
-        unsigned long long bits0 = 0, bits1 = 0;   // ReLU patterns of the two 64-texel tiles, in k_uvmlp_fwd's bit layout
-        uint32_t outv[2][4][16];                   // this layer's outputs (hi | lo << 16) wait in registers until every wave has read its inputs
+        unsigned long long bits0 = 0;              // ReLU pattern of the tile, in k_uvmlp_fwd's bit layout
+        uint32_t outv[2][2][16];                   // this layer's outputs (hi | lo << 16) wait in registers until every wave has read its inputs
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {           // the wave's two 32-column blocks one after the other: 128 accumulator registers
-            f32x16 acc[4], acx[4];
+        for (int nb = 0; nb < 2; ++nb) {           // the wave's two 32-column blocks one after the other: 64 accumulator registers
+            f32x16 acc[2], acx[2];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { acc[a][q] = 0.f; acx[a][q] = 0.f; }
             // weight fragments: block (kb, nbg) at ((kb * 8 + nbg) * 1024) halves, hi[64][8] then lo[64][8]
@@ -438,10 +438,10 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
                 xh = *(const f16x8 *)(p); xl = *(const f16x8 *)(p + 512);
             };
             load_b(0, b0h, b0l); load_b(1, b1h, b1l);
-            f16x8 ah[4], al[4], nah[4], nal[4];
-            auto load_a = [&](int kb, f16x8 (&xh)[4], f16x8 (&xl)[4]) {
+            f16x8 ah[2], al[2], nah[2], nal[2];
+            auto load_a = [&](int kb, f16x8 (&xh)[2], f16x8 (&xl)[2]) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
+                for (int mb = 0; mb < 2; ++mb) {
                     xh[mb] = *(const f16x8 *)(ah_base + mb * 32 * STRIDE + kb * 16);
                     xl[mb] = *(const f16x8 *)(al_base + mb * 32 * STRIDE + kb * 16);
                 }
@@ -450,12 +450,12 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
             // One k-step: the next step's activation fragments (LDS) and the weights two steps ahead (L2) are requested before this
             // step's MFMAs issue — with one wave per SIMD nothing else covers their latency.  The loop walks two steps per trip over
             // the two activation register sets (no copies); only the three small weight sets rotate.
-            auto step = [&](int kb, f16x8 (&ch)[4], f16x8 (&cl)[4], f16x8 (&nh)[4], f16x8 (&nl)[4]) {
+            auto step = [&](int kb, f16x8 (&ch)[2], f16x8 (&cl)[2], f16x8 (&nh)[2], f16x8 (&nl)[2]) {
                 load_b(kb + 2, b2h, b2l);
                 load_a(kb + 1 < nkb ? kb + 1 : kb, nh, nl);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
+                for (int mb = 0; mb < 2; ++mb) {
                     acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[mb], b0h, acc[mb], 0, 0, 0);
                     acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[mb], b0l, acx[mb], 0, 0, 0);
                     acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[mb], b0h, acx[mb], 0, 0, 0);
@@ -471,12 +471,11 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
             if (kb < nkb) step(kb, ah, al, nah, nal);       // K = 48 and 304 are an odd number of 16-deep steps
             const float bv = bias[wave * 64 + nb * 32 + r];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const float v = acc[mb][q] + acx[mb][q] * (1.0f / 2048.0f) + bv;
-                    const unsigned long long on = (unsigned long long)(v > 0.f) << ((nb * 2 + (mb & 1)) * 16 + q);
-                    if (mb < 2) bits0 |= on; else bits1 |= on;
+                    bits0 |= (unsigned long long)(v > 0.f) << ((nb * 2 + mb) * 16 + q);
                     const float y = v > 0.f ? v : 0.f;
                     const f16 yh = (f16)y;
                     const f16 yl = (f16)((y - (float)yh) * 2048.0f);
@@ -488,7 +487,7 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
         for (int nb = 0; nb < 2; ++nb) {
             const int col = wave * 64 + nb * 32 + r;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int o = (mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * STRIDE + EP + col;
@@ -498,9 +497,7 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
         }
         if (saved) {
             unsigned long long *mk = (unsigned long long *)(saved + N * (int64_t)(EP + plan.n_hidden * W));
-            const int64_t nt64 = (N + UVM_TM - 1) / UVM_TM, t64 = (int64_t)blockIdx.x * 2;
-            mk[((int64_t)li * nt64 + t64) * W + tid] = bits0;
-            if (t64 + 1 < nt64) mk[((int64_t)li * nt64 + t64 + 1) * W + tid] = bits1;
+            mk[((int64_t)li * gridDim.x + blockIdx.x) * W + tid] = bits0;
         }
         __syncthreads();
         if (saved) {   // post-ReLU activations [layer][texel][W] as the value the next layer consumes (hi + lo 2^-11)
@@ -518,13 +515,13 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
         }
     }
 
-    // ---- output layer (256 -> out_ch <= 4) on the VALU, 2 threads per texel ------------------------------------------
+    // ---- output layer (256 -> out_ch <= 4) on the VALU, 4 threads per texel ------------------------------------------
     {
-        const int row = tid >> 1, part = tid & 1;
-        const float *ow = packed + plan.out_w_off + part * 128;
+        const int row = tid >> 2, part = tid & 3;
+        const float *ow = packed + plan.out_w_off + part * 64;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < 128; k += 8) {
-            const f16x8 vh = *(const f16x8 *)(phi + row * STRIDE + EP + part * 128 + k), vl = *(const f16x8 *)(plo + row * STRIDE + EP + part * 128 + k);
+        for (int k = 0; k < 64; k += 8) {
+            const f16x8 vh = *(const f16x8 *)(phi + row * STRIDE + EP + part * 64 + k), vl = *(const f16x8 *)(plo + row * STRIDE + EP + part * 64 + k);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float x = (float)vh[j] + (float)vl[j] * (1.0f / 2048.0f);
@@ -534,7 +531,7 @@ __global__ __launch_bounds__(256) void k_uvmlp_fwd16(const float *__restrict__ u
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s[c] += __shfl_xor(s[c], 1, 64);
+        for (int c = 0; c < 4; ++c) { s[c] += __shfl_xor(s[c], 1, 64); s[c] += __shfl_xor(s[c], 2, 64); }
         const int64_t n = n0 + row;
         if (part == 0 && n < N) {
             for (int c = 0; c < plan.out_ch; ++c) {

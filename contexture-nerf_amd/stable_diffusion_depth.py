@@ -280,20 +280,23 @@ class StableDiffusion:
         """Several img2img_step calls (views, possibly of different meshes) denoised in LOCKSTEP as ONE UNet evaluation of batch
         2 x views_per_eval per step: rows [u_0, c_0, u_1, c_1, ...] (every view keeps its own text embeddings, depth, seed, scheduler
         state and fused CFG / PLMS update).  At M = views x 2 x h x w rows every layer is a large GEMM (no split-K slabs, full tiles),
-        which one view at CFG batch 2 cannot offer.  Groups are ALWAYS evaluated at exactly views_per_eval views (a short last group
-        is padded with copies of its last view, whose results are dropped): the executor's plan depends on the row count only and
-        every row's arithmetic is independent of the other rows, so a view's result does not depend on which views share its batch
-        — the atlas of a mesh is the same bits whether it is painted alone or inside a mesh batch.  (It is NOT bit-identical to the
-        batch-2 loop of img2img_step: other tile / split-K plans sum in another order; same tolerance against the oracle.)
-        All calls must share image_size and num_inference_steps / strength (one timestep schedule); otherwise this falls back
-        to img2img_step_multi.  A single call is padded like any short group."""
+        which one view at CFG batch 2 cannot offer: 155 view-steps/s against 145 for three streams of batch 2 and 116 for one (latent 96,
+        plan table tuned for batch 12).
+        Only FULL groups of views_per_eval views are batched; the remaining views (fewer than a group: a rank of a multi-GPU job that
+        owns one or two views) go through img2img_step_multi — streams of batch 2 — because a padded batch would multiply their work.
+        The executor's plan depends on the row count only and every row's arithmetic is independent of the other rows, so inside
+        full groups a view's result does not depend on which views share its batch nor on its position (tested).  It is NOT
+        bit-identical to the batch-2 loop: other tile / split-K plans sum in another order (same tolerance against the oracle).
+        All calls must share image_size and num_inference_steps / strength (one timestep schedule); otherwise everything falls back
+        to img2img_step_multi."""
         n, G = len(calls), int(views_per_eval)
         key = lambda kw: (kw.get('image_size', 512), kw.get('num_inference_steps', 50), kw.get('strength', 0.5), kw.get('latent_mode', False))
-        if n < 1 or G < 2 or 2 * G > 16 or any(key(kw) != key(calls[0]) for kw in calls) or any(kw.get('intermediate_vis') for kw in calls):
+        if n < G or G < 2 or 2 * G > 16 or any(key(kw) != key(calls[0]) for kw in calls) or any(kw.get('intermediate_vis') for kw in calls):
             return self.img2img_step_multi(calls)
+        nfull = (n // G) * G
         jobs, metas = [], []
         with torch.no_grad():
-            for kw in calls:
+            for kw in calls[:nfull]:
                 image_size, latent_mode = kw.get('image_size', 512), kw.get('latent_mode', False)
                 latents, depth_mask, update_mask = self._prepare(kw['inputs'], kw['original_depth_mask'], kw.get('update_mask'),
                                                                  latent_mode, image_size)
@@ -301,10 +304,9 @@ class StableDiffusion:
                                                      kw.get('strength', 0.5), kw.get('num_inference_steps', 50), update_mask,
                                                      kw.get('fixed_seed'), kw.get('guidance_scale', 100)))
                 metas.append(latent_mode)
-            for g0 in range(0, n, G):
+            for g0 in range(0, nfull, G):
                 grp = jobs[g0:g0 + G]
-                pad = [grp[-1]] * (G - len(grp))                       # padded rows: same arithmetic, results dropped
-                ctx = torch.cat([j.text_embeddings for j in grp + pad])
+                ctx = torch.cat([j.text_embeddings for j in grp])
                 steps = len(grp[0].timesteps)
                 if any(len(j.timesteps) != steps or not torch.equal(j.timesteps, grp[0].timesteps) for j in grp):
                     raise L.CtxError("img2img_step_batched: the views of one evaluation must share their timestep schedule")
@@ -313,7 +315,6 @@ class StableDiffusion:
                     for j in grp:
                         x, t = j.model_input()
                         xs.append(x)
-                    xs += [xs[-1]] * len(pad)
                     noise = self.unet(torch.cat(xs), float(t), encoder_hidden_states=ctx)['sample']
                     for v, j in enumerate(grp):
                         j.apply(noise[2 * v:2 * v + 2], t)
@@ -321,6 +322,8 @@ class StableDiffusion:
             for j, lm in zip(jobs, metas):
                 rgb = self.decode_latents(j.latents)
                 outs.append((rgb, j.latents) if lm else (rgb, []))
+        if nfull < n:
+            outs += self.img2img_step_multi(calls[nfull:])
         return outs
 
     def img2img_step_pair(self, calls):

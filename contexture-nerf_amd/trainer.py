@@ -414,7 +414,7 @@ class ConTEXTure:
         j = 0
         while j < len(mine):
             grp = mine[j:j + infl]
-            if len(grp) > 1 or int(getattr(self.cfg.optim, 'views_per_eval', 0)) > 1:
+            if len(grp) > 1:
                 res = self.paint_viewpoints_multi([self.train_views[k] for k in grp], image_size=image_size,
                                                   num_inference_steps=num_inference_steps)
                 for o, (rgb, obj_mask, last) in enumerate(res):

@@ -128,34 +128,40 @@ def test_trainer_view_weights_paint_and_atlas(dev, meshes):
 
 def test_img2img_step_batched_lockstep_views(dev):
     """StableDiffusion.img2img_step_batched: V views denoised in lockstep as ONE UNet evaluation of batch 2V per step.
-    (a) A view's result does not depend on which other views share its batch, nor on its position in it, nor on padding: the
+    (a) Inside full groups a view's result does not depend on which other views share its batch, nor on its position in it: the
         executor's plan depends on the row count only and rows are arithmetically independent  -> torch.equal.
-    (b) Against the batch-2 loop of img2img_step (other tile / split-K plans -> another summation order) the denoised latents agree
-        to the fp16 tolerance of the parity tests, not bit for bit."""
+    (b) Views left over after the full groups go through the batch-2 streams and equal img2img_step bit for bit.
+    (c) Against the batch-2 loop (other tile / split-K plans -> another summation order) the batched latents agree to the fp16
+        tolerance of the parity tests, not bit for bit."""
     sd, _, cfg = _tiny_sd(dev)
     g = torch.Generator().manual_seed(9)
     calls = []
-    for v in range(4):
+    for v in range(5):
         calls.append(dict(text_embeddings=torch.randn(2, 9, cfg['cross_attention_dim'], generator=g).to(dev),
                           inputs=torch.rand(1, 3, 72, 72, generator=g).to(dev), original_depth_mask=torch.rand(1, 1, 72, 72, generator=g).to(dev),
                           guidance_scale=10.0, strength=1.0, num_inference_steps=4, update_mask=torch.ones(1, 1, 72, 72, device=dev),
                           latent_mode=False, fixed_seed=11 + v, image_size=128))
     lat = lambda kw: dict(kw, latent_mode=True, inputs=torch.zeros(1, 4, 16, 16, device=dev))
+    serial = []
+    for k in range(5):
+        kw = lat(calls[k])
+        serial.append(sd.img2img_step(kw['text_embeddings'], kw['inputs'], kw['original_depth_mask'],
+                                      **{kk: vv for kk, vv in kw.items() if kk not in ('text_embeddings', 'inputs', 'original_depth_mask')}))
     a = sd.img2img_step_batched([lat(c) for c in calls[:3]], views_per_eval=3)
-    b = sd.img2img_step_batched([lat(calls[2]), lat(calls[0])], views_per_eval=3)             # other order, padded group
-    c = sd.img2img_step_batched([lat(calls[0])], views_per_eval=3)                            # a single view, padded twice
-    d = sd.img2img_step_batched([lat(c_) for c_ in calls], views_per_eval=3)                  # two groups: 3 + 1 (padded)
-    assert torch.equal(a[0][1], b[1][1]) and torch.equal(a[2][1], b[0][1]) and torch.equal(a[0][1], c[0][1])
-    assert all(torch.equal(a[k][1], d[k][1]) for k in range(3)) and torch.equal(a[0][0], c[0][0])
-    for k in range(4):
-        rgb1, lat1 = sd.img2img_step(calls[k]['text_embeddings'], torch.zeros(1, 4, 16, 16, device=dev), calls[k]['original_depth_mask'],
-                                     **{kk: vv for kk, vv in lat(calls[k]).items() if kk not in ('text_embeddings', 'inputs', 'original_depth_mask')})
-        rel = float((d[k][1] - lat1).norm() / lat1.norm())
-        assert rel < 4e-3 and torch.isfinite(d[k][0]).all(), (k, rel)
+    b = sd.img2img_step_batched([lat(calls[2]), lat(calls[4]), lat(calls[0])], views_per_eval=3)      # other mates, other positions
+    d = sd.img2img_step_batched([lat(c_) for c_ in calls], views_per_eval=3)                        # one full group + two left over
+    assert torch.equal(a[0][1], b[2][1]) and torch.equal(a[2][1], b[0][1]) and torch.equal(a[0][0], b[2][0])
+    assert all(torch.equal(a[k][1], d[k][1]) for k in range(3))
+    assert torch.equal(d[3][1], serial[3][1]) and torch.equal(d[4][1], serial[4][1])                # the remainder: batch-2 streams
+    for k in range(3):
+        rel = float((d[k][1] - serial[k][1]).norm() / serial[k][1].norm())
+        assert 0 < rel < 4e-3 and torch.isfinite(d[k][0]).all(), (k, rel)
     assert not torch.equal(d[0][1], d[1][1])
-    # image-mode calls return (rgb, []) like img2img_step
-    e = sd.img2img_step_batched(calls[:2], views_per_eval=2)
-    assert e[0][0].shape == (1, 3, 128, 128) and e[0][1] == []
+    # fewer views than a group: everything takes the stream path; image-mode calls return (rgb, []) like img2img_step
+    e = sd.img2img_step_batched([lat(calls[0]), lat(calls[1])], views_per_eval=3)
+    assert torch.equal(e[0][1], serial[0][1]) and torch.equal(e[1][1], serial[1][1])
+    f = sd.img2img_step_batched(calls[:2], views_per_eval=2)
+    assert f[0][0].shape == (1, 3, 128, 128) and f[0][1] == []
 
 
 def test_mesh_batch_painter_configs3_on_the_hip_path(dev):

@@ -16,6 +16,7 @@ ap.add_argument("--image", type=int, default=768)
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--meshes", type=int, default=8)
 ap.add_argument("--in-flight", type=int, default=3)
+ap.add_argument("--per-eval", type=int, default=6, help="views denoised in lockstep as one UNet evaluation (0: --in-flight streams)")
 a = ap.parse_args()
 rank, world, dev = D.init()
 names = ["nascar", "spot_triangulated", "bunny", "blub_no_texture", "sphere", "env_sphere"]
@@ -30,6 +31,7 @@ for nm in names:
     cfg.guide.sd_image_size = a.image
     cfg.guide.num_inference_steps = a.steps
     cfg.optim.views_in_flight = a.in_flight
+    cfg.optim.views_per_eval = a.per_eval if a.per_eval > 1 else 0
     tr = ConTEXTure(cfg, device=dev, diffusion=sd)
     tr.text_z = sd.get_text_embeds([cfg.guide.text])
     trainers.append(tr)
@@ -46,7 +48,7 @@ dt = time.perf_counter() - t
 if rank == 0:
     print(json.dumps({"metric": "sec per mesh batch (BASELINE configs[3])", "meshes": names, "views_per_mesh": 6, "n_gpus": world,
                       "items_per_rank": [len(p) for p in bp.plan], "image": a.image, "plms_steps": a.steps,
-                      "views_in_flight": a.in_flight, "sec_total": round(dt, 3), "sec_per_mesh": round(dt / len(names), 3),
+                      "views_in_flight": a.in_flight, "views_per_eval": a.per_eval, "sec_total": round(dt, 3), "sec_per_mesh": round(dt / len(names), 3),
                       "coverage": [round(float((c > 0).float().mean()), 4) for _, c in res],
                       "finite": bool(all(torch.isfinite(at).all() for at, _ in res)),
                       "data": "synthetic (random-init weights, seeded text embeddings; cold: includes first-touch of the workspaces)"}))
