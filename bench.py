@@ -353,8 +353,9 @@ def main():
         }
         out["sec_per_mesh"] = round(mesh_s, 3) if mesh_s is not None else None
         out["sec_per_mesh_note"] = (f"{'MEASURED' if mesh_s is not None else 'NOT MEASURED (' + str(mesh_cover) + ')'}: one ConTEXTure.paint of {a.mesh_path}, {a.mesh_views} views over {world} rank(s), "
-                                    (f"{a.per_eval} views per lockstep evaluation (batch {2 * a.per_eval})" if a.per_eval > 1 else f"{a.in_flight} views in flight") + " per rank, 1200^2 render, 51 UNet evals + VAE decode per view, "
-                                    f"view weights, UV scatter, atlas merge; coverage {mesh_cover}")
+                                    + (f"full groups of {a.per_eval} views per lockstep evaluation (batch {2 * a.per_eval}), the rest " if a.per_eval > 1 else "")
+                                    + f"{a.in_flight} views in flight per rank, 1200^2 render, 51 UNet evals + VAE decode per view, "
+                                    + f"view weights, UV scatter, atlas merge; coverage {mesh_cover}")
         if two is not None:
             out["views_in_flight"] = two
             out["sec_per_mesh_6_views_est_2_in_flight"] = round(-(-6 // world) * (51 * two["2"]["ms_per_step_per_view"] + (vae_ms or 0.0)) / 1e3, 3)

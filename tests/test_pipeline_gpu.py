@@ -155,7 +155,7 @@ def test_img2img_step_batched_lockstep_views(dev):
     assert torch.equal(d[3][1], serial[3][1]) and torch.equal(d[4][1], serial[4][1])                # the remainder: batch-2 streams
     for k in range(3):
         rel = float((d[k][1] - serial[k][1]).norm() / serial[k][1].norm())
-        assert 0 < rel < 4e-3 and torch.isfinite(d[k][0]).all(), (k, rel)
+        assert rel < 4e-3 and torch.isfinite(d[k][0]).all(), (k, rel)         # 0 on this tiny net (the same plans at batch 6); ~1e-3 at full size
     assert not torch.equal(d[0][1], d[1][1])
     # fewer views than a group: everything takes the stream path; image-mode calls return (rgb, []) like img2img_step
     e = sd.img2img_step_batched([lat(calls[0]), lat(calls[1])], views_per_eval=3)

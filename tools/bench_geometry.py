@@ -75,6 +75,15 @@ report("UV scatter plan (bin pixels by atlas tile; once per raster) B=7 @1200^2"
 report("texture_mapping bwd binned (LDS tiles, no global float atomics; cached plan) B=7 @1200^2",
        timeit(lambda: L.check(lib.ctx_texture_mapping_bwd_binned(L.ptr(go), L.ptr(uvc), L.ptr(idx), B, H * W, 3, T, L.ptr(plan), L.ptr(wsb), L.ptr(g), L.stream()))),
        bytes_=B * H * W * (8 + 12 + 8) + 2 * 3 * T * T * 4)
+# the painted-view back-projection proper (ConTEXTure.project_back_scatter: rgb * w and w, C = 4, int64 2^-32 sums, cached plan)
+go4 = torch.rand(B, H, W, 4, device=dev)
+acc = torch.zeros(4, T, T, dtype=torch.int64, device=dev)
+report("UV back-projection scatter, fixed point (C=4: rgb*w + w; int64 sums; cached plan) B=7 @1200^2",
+       timeit(lambda: L.check(lib.ctx_uv_scatter_fixed(L.ptr(go4), L.ptr(uvc), L.ptr(idx), B, H * W, 4, T, L.ptr(plan), 32, L.ptr(acc), L.stream()))),
+       bytes_=B * H * W * (8 + 16 + 8) + 2 * 4 * T * T * 8)
+report("UV back-projection scatter, fixed point, no plan (one int64 atomic per tap) B=7 @1200^2",
+       timeit(lambda: L.check(lib.ctx_uv_scatter_fixed(L.ptr(go4), L.ptr(uvc), L.ptr(idx), B, H * W, 4, T, None, 32, L.ptr(acc), L.stream())), 3),
+       bytes_=B * H * W * (8 + 16 + 8) + 2 * 4 * T * T * 8)
 fnp = fn.permute(0, 2, 1).contiguous()
 idx6 = idx[1:, None].contiguous(); fn6 = fnp[1:].contiguous()
 report("view weights (scatter_max seam) B=6 @1200^2", timeit(lambda: vw.view_weight_masks(idx6, fn6)), bytes_=6 * H * W * (8 + 8 + 1) + 6 * F_ * 4)
@@ -83,7 +92,10 @@ report("create_face_view_map B=6 @1200^2", timeit(lambda: L.check(0) or vw.creat
 torch.manual_seed(0)
 net = rnh.NeRF2D(D=8, W=256, input_ch=42, output_ch=3, skips=[4]).to(dev)
 net.packed()
+report("texture field (embed+NeRF2D+tanh) 1024^2 atlas, split-fp16 MFMA (3 passes; FLOP = the network's, not the passes')", timeit(lambda: (setattr(net, "_tex_cache", None), net.texture_map(1024))[1], 5), flops=962048.0 * 1024 * 1024, peak=2500.0 / 3)
+os.environ["CTX_UVMLP_EXACT_F32"] = "1"
 report("texture field (embed+NeRF2D+tanh) 1024^2 atlas, exact-f32 MFMA", timeit(lambda: (setattr(net, "_tex_cache", None), net.texture_map(1024))[1], 5), flops=962048.0 * 1024 * 1024, peak=157.3)
+os.environ.pop("CTX_UVMLP_EXACT_F32")
 R, S = 512 * 512, 128
 raw = torch.randn(R, S, 4, device=dev); z = torch.sort(torch.rand(R, S, device=dev) * 4 + 2, -1).values; d = torch.randn(R, 3, device=dev)
 rr, zz, dd = raw.contiguous(), z.contiguous(), d.contiguous()
