@@ -46,6 +46,7 @@ struct UvmPlan {
     UvmLayer layer[UVM_MAX_LAYERS];
     int64_t wt_off[UVM_MAX_LAYERS];   // layer i >= 1: W_i[:, hidden part]^T packed as an MFMA B operand (backward chain)
     int64_t w16_off[UVM_MAX_LAYERS];  // layer i: the same weights as two fp16 planes (hi, lo x 2^11) in 32x32x16 B-fragment order, or -1
+    int64_t wt16_off[UVM_MAX_LAYERS]; // layer i >= 1: wt_off's operand as two fp16 planes (backward chain of k_uvmlp_dgrad16), or -1
 };
 
 static int uvm_build_plan(int D, int W, int input_ch, int output_ch, int skip, UvmPlan &p, int64_t &total)
@@ -70,6 +71,10 @@ static int uvm_build_plan(int D, int W, int input_ch, int output_ch, int skip, U
     for (int i = 0; i < D; ++i) {
         if (W == 256 && EP == UVM_EPAD && p.layer[i].kp % 16 == 0) { p.w16_off[i] = off; off += (int64_t)p.layer[i].kp * W; }
         else p.w16_off[i] = -1;
+    }
+    for (int i = 0; i < D; ++i) {
+        if (i >= 1 && W == 256 && EP == UVM_EPAD) { p.wt16_off[i] = off; off += (int64_t)W * W; }
+        else p.wt16_off[i] = -1;
     }
     total = off;
     return 0;
@@ -147,6 +152,22 @@ __global__ void k_uvm_pack16(const float *__restrict__ w, int W, int kin, int kp
     dw[blk * 1024 + 512 + lane * 8 + j] = lo;
 }
 
+// backward-chain operand of k_uvmlp_dgrad16: block (kb over the contraction index n, nb over the output column k) = hi[64][8] | lo[64][8],
+// lane (r, h) element j = w[kb*16 + 8h + j][off + nb*32 + r]
+__global__ void k_uvm_pack16_t(const float *__restrict__ w, int W, int kin, int off, f16 *__restrict__ dw)
+{
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)W * W) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    const int64_t blk = idx >> 9;
+    const int nb = blk % (W / 32), kb = blk / (W / 32);
+    const int r = lane & 31, h = lane >> 5;
+    const float v = w[(int64_t)(kb * 16 + 8 * h + j) * kin + off + nb * 32 + r];
+    const f16 hi = (f16)v;
+    dw[blk * 1024 + lane * 8 + j] = hi;
+    dw[blk * 1024 + 512 + lane * 8 + j] = (f16)((v - (float)hi) * 2048.0f);
+}
+
 __global__ void k_uvm_pack_out(const float *__restrict__ w, const float *__restrict__ b, int W, int out_ch,
                                float *__restrict__ dw, float *__restrict__ db)
 {
@@ -173,6 +194,9 @@ extern "C" int32_t ctx_uvmlp_pack(const float *const *ws, const float *const *bs
         if (i >= 1)
             hipLaunchKernelGGL(k_uvm_pack_t, dim3((unsigned)cdiv64((int64_t)W * W, 256)), dim3(256), 0, s, ws[i], W, kin,
                                i == skip + 1 ? input_ch : 0, dst + p.wt_off[i]);
+        if (p.wt16_off[i] >= 0)
+            hipLaunchKernelGGL(k_uvm_pack16_t, dim3((unsigned)cdiv64((int64_t)W * W, 256)), dim3(256), 0, s, ws[i], W, kin, i == skip + 1 ? input_ch : 0,
+                               (f16 *)(dst + p.wt16_off[i]));
         if (p.w16_off[i] >= 0)
             hipLaunchKernelGGL(k_uvm_pack16, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, ws[i], W, kin, p.layer[i].kp, input_ch, p.epad, mode,
                                (f16 *)(dst + p.w16_off[i]));
@@ -785,6 +809,223 @@ __global__ __launch_bounds__(W, 2) void k_uvmlp_dgrad(const float *__restrict__ 
     }
 }
 
+// ---- the dZ chain on the 16-bit matrix pipe with split operands (the backward twin of k_uvmlp_fwd16) ---------------------------------
+// Same phases and outputs as k_uvmlp_dgrad<256>; the chain's GEMMs dA_{i-1} = dZ_i . W_i[:, hidden] run as three v_mfma_f32_32x32x16_f16
+// passes over (hi, lo) planes of dZ (LDS) and of the weights (L2).  Gradients have no natural scale (1e-8 under a mean-reduced loss):
+// every op of the chain is linear, so the tile's draw is multiplied by 2^e with e from a device reduction of max|grad| (the largest
+// draw lands near 16: room for a 4 000-fold growth through the layers before fp16 overflows, 2^-35 of the maximum still resolved), and
+// dZ goes to HBM multiplied by 2^-e (exact).
+struct UvmCtl { uint32_t absmax_raw, absmax_tex; int32_t e; int32_t pad; };
+__global__ __launch_bounds__(256) void k_uvm_absmax(const float *__restrict__ a, int64_t na, const float *__restrict__ b, int64_t nb_, UvmCtl *__restrict__ ctl)
+{
+    uint32_t ma = 0, mb = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a) for (int64_t i = i0; i < na; i += stride) ma = max(ma, __float_as_uint(a[i]) & 0x7fffffffu);
+    if (b) for (int64_t i = i0; i < nb_; i += stride) mb = max(mb, __float_as_uint(b[i]) & 0x7fffffffu);
+    for (int o = 32; o; o >>= 1) { ma = max(ma, (uint32_t)__shfl_xor((int)ma, o)); mb = max(mb, (uint32_t)__shfl_xor((int)mb, o)); }
+    if ((threadIdx.x & 63) == 0) { if (ma) atomicMax(&ctl->absmax_raw, ma); if (mb) atomicMax(&ctl->absmax_tex, mb); }
+}
+__global__ void k_uvm_scale(UvmCtl *ctl)
+{
+    // |draw| <= |grad_raw| + 0.5 |grad_tex| (tanh' <= 1); non-finite or zero gradients: no scaling (they propagate as they are)
+    const float bound = __uint_as_float(ctl->absmax_raw) + 0.5f * __uint_as_float(ctl->absmax_tex);
+    int e = 0;
+    if (bound > 0.f && bound < INFINITY) { int x; (void)frexpf(bound, &x); e = 4 - x; }
+    ctl->e = e;
+}
+
+#define UVM16B_LO 264             // halves: dZ's lo plane behind its hi plane (256 + 8)
+#define UVM16B_STRIDE 536         // halves per row pair: 1072 bytes = 16 x odd
+__global__ __launch_bounds__(256, 2) void k_uvmlp_dgrad16(const float *__restrict__ grad_raw, const float *__restrict__ grad_tex,
+                                                          const float *__restrict__ raw, int64_t N, const float *__restrict__ packed,
+                                                          UvmPlan plan, const float *__restrict__ saved, float *__restrict__ dz,
+                                                          float *__restrict__ part_w, float *__restrict__ part_b, const UvmCtl *__restrict__ ctl)
+{
+    constexpr int W = 256, STRIDE = UVM16B_STRIDE, C4N = W / 4;
+    extern __shared__ __attribute__((aligned(16))) f16 gp[];       // [64][hi 264 | lo 264 | 8] halves, then dr[64][4] floats
+    f16 *ghi = gp, *glo = gp + UVM16B_LO;
+    float *dr = (float *)(gp + UVM_TM * STRIDE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int c4 = tid % C4N, rg = tid / C4N;
+    const int D = plan.n_hidden;
+    const float *acts = saved + N * plan.epad;
+    const unsigned long long *masks = (const unsigned long long *)(saved + N * (int64_t)(plan.epad + D * W));
+    const int e = ctl->e;
+
+    float wo[4][4], gwo[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wo[c][j] = c < plan.out_ch ? packed[plan.out_w_off + c * W + c4 * 4 + j] : 0.f;
+            gwo[c][j] = 0.f;
+        }
+    float gbo = 0.f;
+
+    const int64_t ntiles = (N + UVM_TM - 1) / UVM_TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n0 = tile * UVM_TM;
+        for (int i = tid; i < UVM_TM * 4; i += 256) {
+            int t = i >> 2, c = i & 3;
+            int64_t n = n0 + t;
+            float v = 0.f;
+            if (n < N && c < plan.out_ch) {
+                if (grad_raw) v = grad_raw[n * plan.out_ch + c];
+                if (grad_tex) {
+                    float y = tanhf(raw[n * plan.out_ch + c]);
+                    v += grad_tex[(int64_t)c * N + n] * 0.5f * (1.0f - y * y);
+                }
+            }
+            dr[i] = v;
+            gbo += v;
+        }
+        __syncthreads();
+        // ---- output layer on the VALU (f32): dA = draw . Wout, dWout += draw^T . A, dZ = dA * (A > 0) -> HBM as is, LDS scaled and split
+        {
+            const float *a_top = acts + (int64_t)(D - 1) * N * W;
+            float *dz_top = dz + (int64_t)(D - 1) * N * W;
+#pragma unroll 4
+            for (int p = 0; p < UVM_TM / 4; ++p) {
+                int t = p * 4 + rg;
+                int64_t n = n0 + t;
+                int64_t nc = n < N ? n : N - 1;
+                float4 a = *(const float4 *)(a_top + nc * W + c4 * 4);
+                float4 d = *(const float4 *)(dr + t * 4);
+                const float av[4] = {a.x, a.y, a.z, a.w}, dv[4] = {d.x, d.y, d.z, d.w};
+                float o[4];
+                f16x4 oh, ol;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float da = dv[0] * wo[0][j];
+                    da = fmaf(dv[1], wo[1][j], da);
+                    da = fmaf(dv[2], wo[2][j], da);
+                    da = fmaf(dv[3], wo[3][j], da);
+                    o[j] = av[j] > 0.f ? da : 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gwo[c][j] = fmaf(dv[c], av[j], gwo[c][j]);
+                    const float sv = ldexpf(o[j], e);
+                    oh[j] = (f16)sv;
+                    ol[j] = (f16)((sv - (float)oh[j]) * 2048.0f);
+                }
+                *(f16x4 *)(ghi + t * STRIDE + c4 * 4) = oh;
+                *(f16x4 *)(glo + t * STRIDE + c4 * 4) = ol;
+                if (n < N) *(float4 *)(dz_top + n * W + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __syncthreads();
+        // ---- hidden layers, last to second ------------------------------------------------------------------------------
+        for (int li = D - 1; li >= 1; --li) {
+            float *dz_prev = dz + (int64_t)(li - 1) * N * W;
+            const unsigned long long relu_bits = masks[((int64_t)(li - 1) * ntiles + tile) * W + tid];
+            const f16 *ah_base = ghi + r * STRIDE + 8 * h, *al_base = glo + r * STRIDE + 8 * h;
+            uint32_t outv[2][2][16];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 acc[2], acx[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { acc[a][q] = 0.f; acx[a][q] = 0.f; }
+                const f16 *wbase = (const f16 *)(packed + plan.wt16_off[li]) + (size_t)(wave * 2 + nb) * 1024 + lane * 8;
+                constexpr int nkb = W / 16;
+                f16x8 b0h, b0l, b1h, b1l, b2h, b2l;
+                auto load_b = [&](int kb, f16x8 &xh, f16x8 &xl) {
+                    const f16 *p = wbase + (size_t)uvm_opaque(kb < nkb ? kb : nkb - 1) * 8 * 1024;
+                    xh = *(const f16x8 *)(p); xl = *(const f16x8 *)(p + 512);
+                };
+                load_b(0, b0h, b0l); load_b(1, b1h, b1l);
+                f16x8 ah[2], al[2], nah[2], nal[2];
+                auto load_a = [&](int kb, f16x8 (&xh)[2], f16x8 (&xl)[2]) {
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        xh[mb] = *(const f16x8 *)(ah_base + mb * 32 * STRIDE + kb * 16);
+                        xl[mb] = *(const f16x8 *)(al_base + mb * 32 * STRIDE + kb * 16);
+                    }
+                };
+                load_a(0, ah, al);
+                auto step = [&](int kb, f16x8 (&ch)[2], f16x8 (&cl)[2], f16x8 (&nh)[2], f16x8 (&nl)[2]) {
+                    load_b(kb + 2, b2h, b2l);
+                    load_a(kb + 1 < nkb ? kb + 1 : kb, nh, nl);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[mb], b0h, acc[mb], 0, 0, 0);
+                        acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[mb], b0l, acx[mb], 0, 0, 0);
+                        acx[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[mb], b0h, acx[mb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    b0h = b1h; b0l = b1l; b1h = b2h; b1l = b2l;
+                };
+                for (int kb = 0; kb < nkb; kb += 2) {
+                    step(kb, ah, al, nah, nal);
+                    step(kb + 1, nah, nal, ah, al);
+                }
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const bool on = (relu_bits >> ((nb * 2 + mb) * 16 + q)) & 1ull;
+                        const float y = on ? acc[mb][q] + acx[mb][q] * (1.0f / 2048.0f) : 0.f;
+                        const f16 yh = (f16)y;
+                        const f16 yl = (f16)((y - (float)yh) * 2048.0f);
+                        outv[nb][mb][q] = (uint32_t)__builtin_bit_cast(unsigned short, yh) | ((uint32_t)__builtin_bit_cast(unsigned short, yl) << 16);
+                    }
+            }
+            __syncthreads();                     // all fragment reads of dZ_li (and the row copies of it below) are done
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int col = wave * 64 + nb * 32 + r;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int o = (mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * STRIDE + col;
+                        ((unsigned short *)ghi)[o] = (unsigned short)(outv[nb][mb][q] & 0xffffu);
+                        ((unsigned short *)glo)[o] = (unsigned short)(outv[nb][mb][q] >> 16);
+                    }
+            }
+            __syncthreads();
+            // whole rows of dZ_{li-1} to HBM, unscaled; the next layer's fragment reads run alongside (both only read)
+#pragma unroll 4
+            for (int p = 0; p < UVM_TM / 4; ++p) {
+                int t = p * 4 + rg;
+                int64_t n = n0 + t;
+                if (n < N) {
+                    const f16x4 vh = *(const f16x4 *)(ghi + t * STRIDE + c4 * 4), vl = *(const f16x4 *)(glo + t * STRIDE + c4 * 4);
+                    float4 o;
+                    o.x = ldexpf((float)vh[0] + (float)vl[0] * (1.0f / 2048.0f), -e); o.y = ldexpf((float)vh[1] + (float)vl[1] * (1.0f / 2048.0f), -e);
+                    o.z = ldexpf((float)vh[2] + (float)vl[2] * (1.0f / 2048.0f), -e); o.w = ldexpf((float)vh[3] + (float)vl[3] * (1.0f / 2048.0f), -e);
+                    *(float4 *)(dz_prev + n * W + c4 * 4) = o;
+                }
+            }
+        }
+        __syncthreads();                         // the last row copies read the planes before the next tile overwrites them
+    }
+    // ---- output-layer gradients of this workgroup: fold the 4 row groups, one partial row per channel ----
+    float *gf = (float *)gp;                     // 16 x 256 floats
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gf[(rg * 4 + c) * W + c4 * 4 + j] = gwo[c][j];
+    __syncthreads();
+    for (int c = 0; c < 4; ++c) {
+        float s = gf[(0 * 4 + c) * W + tid];
+        s += gf[(1 * 4 + c) * W + tid];
+        s += gf[(2 * 4 + c) * W + tid];
+        s += gf[(3 * 4 + c) * W + tid];
+        part_w[((int64_t)blockIdx.x * 4 + c) * W + tid] = s;
+    }
+    dr[tid] = gbo;
+    __syncthreads();
+    if (tid < 4) {
+        float s = 0.f;
+        for (int i = tid; i < W; i += 4) s += dr[i];
+        part_b[(int64_t)blockIdx.x * 4 + tid] = s;
+    }
+}
+
 // dW[rows x cols] = dZ^T . In over the texel range of this workgroup.  Waves WR x WC, wave tile (32 NI) x (32 NJ).
 // Row strides are compile-time (LDZ = W = rows, LDIN = W or 48) so the operand loads of a whole k-step group hang off two
 // running pointers with immediate offsets; only the last, ragged texel range takes the bounds-checked path.
@@ -972,6 +1213,7 @@ extern "C" int64_t ctx_uvmlp_bwd_ws_bytes(int64_t N, int32_t D, int32_t W)
     b += uvm_align((int64_t)UVM_WG_GROUPS_EMB * W * 4);                  // bias slabs
     b += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * W * 4);                 // output-layer weight partials
     b += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * 4);                     // output-layer bias partials
+    b += 256;                                                            // control words of the split-fp16 chain (gradient scale)
     return b;
 }
 
@@ -1005,13 +1247,28 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
     float *slab = (float *)wp;        wp += uvm_align((int64_t)UVM_WG_GROUPS * W * (W > 64 ? W : 64) * 4);
     float *bslab = (float *)wp;       wp += uvm_align((int64_t)UVM_WG_GROUPS_EMB * W * 4);
     float *part_w = (float *)wp;      wp += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * W * 4);
-    float *part_b = (float *)wp;
+    float *part_b = (float *)wp;      wp += uvm_align((int64_t)UVM_DGRAD_GRID * 4 * 4);
+    UvmCtl *ctl = (UvmCtl *)wp;
 
     // ---- phase 1: the dZ chain ----
     int64_t ntiles = cdiv64(N, UVM_TM);
     int dg = (int)(ntiles < UVM_DGRAD_GRID ? ntiles : UVM_DGRAD_GRID);
     size_t lds = (size_t)(UVM_TM * (W + 4) + UVM_TM * 4) * 4;
-    if (W == 256) {
+    bool fast = dims == 2 && W == 256 && p.epad == UVM_EPAD;
+    {
+        const char *ex = getenv("CTX_UVMLP_EXACT_F32");
+        if (ex && ex[0] == '1') fast = false;
+        for (int i = 1; i < D && fast; ++i) fast = p.wt16_off[i] >= 0;
+    }
+    if (fast) {
+        // split-fp16 chain: scale from max|grad| on the device, then the same phases as the f32 kernel
+        (void)hipMemsetAsync(ctl, 0, sizeof(UvmCtl), s);
+        hipLaunchKernelGGL(k_uvm_absmax, dim3(512), dim3(256), 0, s, grad_raw, grad_raw ? N * output_ch : 0, grad_tex, grad_tex ? N * output_ch : 0, ctl);
+        hipLaunchKernelGGL(k_uvm_scale, dim3(1), dim3(1), 0, s, ctl);
+        const size_t lds16 = (size_t)UVM_TM * UVM16B_STRIDE * sizeof(f16) + UVM_TM * 4 * 4;
+        (void)hipFuncSetAttribute((const void *)k_uvmlp_dgrad16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        hipLaunchKernelGGL(k_uvmlp_dgrad16, dim3(dg), dim3(256), lds16, s, grad_raw, grad_tex, raw, N, pk, p, saved, dz, part_w, part_b, ctl);
+    } else if (W == 256) {
         (void)hipFuncSetAttribute((const void *)k_uvmlp_dgrad<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_uvmlp_dgrad<256>, dim3(dg), dim3(256), lds, s, grad_raw, grad_tex, raw, N, pk, p, saved, dz, part_w, part_b);
     } else if (W == 128) {
