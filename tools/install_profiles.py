@@ -2,12 +2,12 @@
 """Copy what tools/refresh_profiles.sh produced (gpurun_out/prof_refresh/) into profiles/ (names truncated, noise stripped)."""
 import csv, glob, shutil, collections, os
 O = 'gpurun_out/prof_refresh'
-R = os.environ.get('ROUND', 'r02')
+R = os.environ.get('ROUND', 'r03')
 shutil.copy(f'{O}/{R}_bench_default.json', f'profiles/{R}_bench_default.json')
 shutil.copy(f'{O}/traffic.json', f'profiles/{R}_pmc_traffic.json')
 shutil.copy(f'{O}/{R}_bench_by_kernel_and_grid.txt', f'profiles/{R}_bench_by_kernel_and_grid.txt')
 for f in (f'{R}_mesh_bench.json', f'{R}_views_in_flight.txt', f'{R}_uvmlp_bench.json', f'{R}_volume_bench.json', f'{R}_zero123_bench.json', f'{R}_sds_loop_bench.json',
-          f'{R}_mesh_batch_bench.json', f'{R}_bench_mesh_mode.json', f'{R}_gemm_square.txt'):
+          f'{R}_mesh_batch_bench.json', f'{R}_bench_mesh_mode.json', f'{R}_gemm_square.txt', f'{R}_views_batched.txt', f'{R}_uvmlp_bench_exact_f32.json'):
     if os.path.exists(f'{O}/{f}'):
         shutil.copy(f'{O}/{f}', f'profiles/{f}')
 for src, dst in ((f'{O}/{R}_geometry_bench.jsonl', f'profiles/{R}_geometry_bench.jsonl'), (f'{O}/{R}_gemm_layers.txt', f'profiles/{R}_gemm_layers.txt')):
