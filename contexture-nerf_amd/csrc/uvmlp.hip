@@ -1168,122 +1168,6 @@ void k_uvmlp_wgrad(const float *__restrict__ dz, const float *__restrict__ in, i
     }
 }
 
-// The hidden layers' weight gradients dW = dZ^T . In (256 x 256, contraction over the texels) on the 16-bit matrix pipe with the f32
-// operands split THREE-WAY-PRODUCT style in bf16: x = b0 + b1 + O(2^-16 x) with b0 = the top 16 bits of x (truncated, so x - b0 is exact)
-// and b1 = bf16_rn(x - b0); a.w = a0.w0 + a0.w1 + a1.w0 (the a1.w1 term is 2^-16 of the product) as three v_mfma_f32_32x32x16_bf16 passes
-// into ONE fp32 accumulator set — bf16 keeps fp32's exponent range, so gradients need no scaling and the wave tile stays the f32 kernel's
-// 128 x 128.  The per-product error (2^-16, unbiased: b1 is rounded to nearest) averages over the ~4 000 texels of a workgroup's range and
-// the fixed-order slab sum.  No LDS and no transposes either: a lane's fragment — 8 consecutive texels of one feature — is 8 dword loads
-// that are each a 128-byte row segment across the half-wave, exactly the loads the f32 kernel makes for the same 16 texels.
-typedef __bf16 uvm_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void uvm_split_bf16(const float (&x)[8], uvm_bf16x8 &p0, uvm_bf16x8 &p1)
-{
-    uint32_t hi[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const uint32_t u0 = __float_as_uint(x[2 * m]), u1 = __float_as_uint(x[2 * m + 1]);
-        hi[m] = (u0 >> 16) | (u1 & 0xffff0000u);
-    }
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    p0 = __builtin_bit_cast(uvm_bf16x8, (u32x4){hi[0], hi[1], hi[2], hi[3]});
-#pragma unroll
-    for (int j = 0; j < 8; ++j) p1[j] = (__bf16)(x[j] - __uint_as_float(__float_as_uint(x[j]) & 0xffff0000u));
-}
-
-__global__ __launch_bounds__(256) void k_uvmlp_wgrad16(const float *__restrict__ dz, const float *__restrict__ in, int64_t N, int64_t chunk,
-                                                       float *__restrict__ slab, float *__restrict__ bslab)
-{
-    constexpr int NI = 4, NJ = 4, LD = 256, WC = 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wr = wave / WC, wc = wave % WC;
-    const int row0 = wr * NI * 32, col0 = wc * NJ * 32;
-    const int64_t t_begin = (int64_t)blockIdx.x * chunk;
-    const int64_t t_end = t_begin + chunk < N ? t_begin + chunk : N;
-
-    f32x16 acc[NI][NJ];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    float bs[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) bs[i] = 0.f;
-
-    // one k-step = 16 texels: this lane's texels t + 8h .. t + 8h + 7 of feature row0 + 32 i + r (dZ) / col0 + 32 j + r (In).
-    // ONE set of raw registers: a block's next-step loads are issued as soon as the block has been converted, so they have a whole
-    // step of MFMAs (48 x 32 cycles) to land; only the four dZ conversions at the head of a step are not under MFMAs.
-    float ra[NI][8], rb[NJ][8];
-    const bool whole = t_begin + chunk <= N;                            // no bounds checks on whole ranges (chunk % 16 == 0)
-    auto fetch_a = [&](int64_t t, int i) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int64_t tt = t + 8 * h + k;
-            const bool ok = whole || tt < t_end;
-            const float v = dz[((whole || tt < N) ? tt : N - 1) * LD + row0 + r + i * 32];
-            ra[i][k] = ok ? v : 0.f;
-        }
-    };
-    auto fetch_b = [&](int64_t t, int j) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int64_t tt = t + 8 * h + k;
-            const bool ok = whole || tt < t_end;
-            const float v = in[((whole || tt < N) ? tt : N - 1) * LD + col0 + r + j * 32];
-            rb[j][k] = ok ? v : 0.f;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < NI; ++i) fetch_a(t_begin, i);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) fetch_b(t_begin, j);
-    for (int64_t t = t_begin; t < t_end; t += 16) {
-        const int64_t tn = t + 16 < t_end ? t + 16 : t;                 // the last step refetches its own rows (unused)
-        uvm_bf16x8 a0[NI], a1[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            uvm_split_bf16(ra[i], a0[i], a1[i]);
-            float sacc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sacc += ra[i][k];
-            bs[i] += sacc;
-            fetch_a(tn, i);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            uvm_bf16x8 b0, b1;
-            uvm_split_bf16(rb[j], b0, b1);
-            fetch_b(tn, j);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0, acc[i][j], 0, 0, 0);
-            }
-        }
-    }
-    float *sl = slab + (int64_t)blockIdx.x * 256 * 256;
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                int n = row0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                sl[n * 256 + col0 + j * 32 + r] = acc[i][j][q];
-            }
-    if (wc == 0 && bslab) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float v = bs[i] + __shfl_xor(bs[i], 32, 64);
-            if (h == 0) bslab[(int64_t)blockIdx.x * 256 + row0 + i * 32 + r] = v;
-        }
-    }
-}
-
 // out[n][col_off + k] = sum_g slab[g][n][k]  (fixed order), k < out_cols.  One thread per (4 columns, quarter of the groups):
 // 16-byte loads, the four quarters folded through LDS in a fixed order.  cols_pad % 4 == 0.
 __global__ __launch_bounds__(256) void k_uvm_reduce(const float *__restrict__ slab, int G, int64_t stride, int rows, int cols_pad,
@@ -1415,9 +1299,7 @@ extern "C" int32_t ctx_uvmlp_bwd(const float *grad_raw, const float *grad_tex, c
         const bool has_hid = li != 0;
         if (has_hid) {
             const float *in = acts + (int64_t)(li - 1) * N * W;
-            if (W == 256 && fast) {
-                hipLaunchKernelGGL(k_uvmlp_wgrad16, dim3(G), dim3(256), 0, s, dzl, in, N, chunk, slab, bslab);
-            } else if (W == 256) {
+            if (W == 256) {
                 if (wg8) uvm_launch_wgrad<2, 4, 4, 2, 256, 256, 256>(G, dzl, in, N, chunk, slab, bslab, s);
                 else uvm_launch_wgrad<2, 2, 4, 4, 256, 256, 256>(G, dzl, in, N, chunk, slab, bslab, s);
             } else if (W == 128) uvm_launch_wgrad<2, 2, 2, 2, 128, 128, 128>(G, dzl, in, N, chunk, slab, bslab, s);
