@@ -720,6 +720,34 @@ def test_project_back_scatter_vs_oracle(dev, meshes):
     assert float(as_float[3].sum()) > 1000
 
 
+def test_uv_back_projection_default_sizes_bit_exact(dev, meshes):
+    """The UV back-projection at the reference's default sizes: nascar, the 7 Zero123++ views rastered at 1200^2 (src/configs/train_config.py:11),
+    rgb * weight and weight scattered into the 1024^2 atlas (:63) — int64 sums bit-equal to the integer oracle, through the cached tile
+    plan, twice (accumulating), and per view == all views at once (what makes the sharded paint independent of the dealing)."""
+    from contexture_nerf_amd import kal
+    verts, f, cam, proj = _scene(meshes, "nascar", 7)
+    g_cam, g_img, g_fn = kal.render.mesh.prepare_vertices(torch.tensor(verts, device=dev), torch.tensor(f, device=dev),
+                                                          torch.tensor(proj), camera_transform=torch.tensor(cam, device=dev))
+    uva = _uv_attr(meshes, "nascar", f.shape[0])
+    H = W = 1200; T = 1024
+    _, uv, idx, _ = kal.render.mesh.rasterize_fused(H, W, g_cam, g_img, torch.tensor(uva, device=dev), g_fn)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    rgb = torch.rand(7, H, W, 3, generator=gen, device=dev)
+    w = (torch.rand(7, H, W, 1, generator=gen, device=dev) > 0.3).float()
+    vals = torch.cat([rgb * w, w], -1).contiguous()
+    acc = torch.zeros(4, T, T, dtype=torch.int64, device=dev)
+    kal.scatter_fixed(vals, uv, idx, acc)
+    want = og.uv_scatter_fixed(vals.cpu().numpy(), uv.cpu().numpy(), idx.cpu().numpy(), T, kal.SCATTER_FRAC_BITS)
+    assert np.array_equal(acc.cpu().numpy(), want), f"{(acc.cpu().numpy() != want).sum()} texel sums differ"
+    assert float((want[3] > 0).mean()) > 0.05
+    per_view = torch.zeros_like(acc)
+    for b in (3, 0, 6, 1, 5, 2, 4):                                  # any order of views
+        kal.scatter_fixed(vals[b:b + 1].contiguous(), uv[b:b + 1].contiguous(), idx[b:b + 1].contiguous(), per_view)
+    assert torch.equal(per_view, acc)
+    kal.scatter_fixed(vals, uv, idx, acc)
+    assert torch.equal(acc, 2 * per_view)
+
+
 @pytest.mark.parametrize("B,H,W,C,T", [(1, 64, 64, 4, 100), (2, 300, 300, 3, 2304), (1, 128, 128, 6, 64)])
 def test_uv_scatter_fixed_small_and_planless(dev, B, H, W, C, T):
     """ctx_uv_scatter_fixed on rasters below the binning threshold, on an atlas beyond the plan's LDS histogram (T = 2304 > 2272:
