@@ -823,7 +823,15 @@ __global__ __launch_bounds__(256) void k_uvm_absmax(const float *__restrict__ a,
     if (a) for (int64_t i = i0; i < na; i += stride) ma = max(ma, __float_as_uint(a[i]) & 0x7fffffffu);
     if (b) for (int64_t i = i0; i < nb_; i += stride) mb = max(mb, __float_as_uint(b[i]) & 0x7fffffffu);
     for (int o = 32; o; o >>= 1) { ma = max(ma, (uint32_t)__shfl_xor((int)ma, o)); mb = max(mb, (uint32_t)__shfl_xor((int)mb, o)); }
-    if ((threadIdx.x & 63) == 0) { if (ma) atomicMax(&ctl->absmax_raw, ma); if (mb) atomicMax(&ctl->absmax_tex, mb); }
+    __shared__ uint32_t s_m[2][4];                 // one atomic pair per workgroup (atomics on one address serialise)
+    if ((threadIdx.x & 63) == 0) { s_m[0][threadIdx.x >> 6] = ma; s_m[1][threadIdx.x >> 6] = mb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ma = max(max(s_m[0][0], s_m[0][1]), max(s_m[0][2], s_m[0][3]));
+        mb = max(max(s_m[1][0], s_m[1][1]), max(s_m[1][2], s_m[1][3]));
+        if (ma) atomicMax(&ctl->absmax_raw, ma);
+        if (mb) atomicMax(&ctl->absmax_tex, mb);
+    }
 }
 __global__ void k_uvm_scale(UvmCtl *ctl)
 {
