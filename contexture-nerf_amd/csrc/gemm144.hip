@@ -289,10 +289,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf, acc[i][j], 0, 0, 0);
         };
-        // wave-priority experiments: 1 = the later half of the waves (arbitration losers) at priority 1 for the whole loop,
-        // 2 = every wave raises its priority around its MFMA rows, 3 = odd waves at priority 1
-        if (a.prio == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-        if (a.prio == 3 && (wave & 1)) __builtin_amdgcn_s_setprio(1);
         rd(xp_, wp_, smem, 0);
         // cur = half-fragments A of this stage (loaded), nxt = where the next stage's go
         // `steady` (a std::integral_constant): the loop's middle, where a stage is still to be issued (go), a next stage exists
@@ -313,7 +309,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             const f16 *sc = smem + buf * G144_STAGE, *sn = smem + nb_ * G144_STAGE;
             const bool more = ST || kt + 1 < nk;
             if (go) issue_begin();
-            if (a.prio == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 mrow(xc[i], wc, i);
@@ -336,7 +331,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (a.prio == 2) __builtin_amdgcn_s_setprio(0);
             buf = nb_;
         };
         using T1 = std::integral_constant<bool, true>;
@@ -463,10 +457,8 @@ int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
     a.splitk = S;
     const double wbytes = (double)a.N * a.K, xbytes = (double)a.M * (conv ? a.Cin : a.K);
     a.mfast = wbytes > xbytes ? 1 : 0;
-    static int stg = -1, prio = -1;
+    static int stg = -1;
     if (stg < 0) { const char *e = getenv("CTX_G144_STAGE"); stg = e ? atoi(e) : 1; }
-    if (prio < 0) { const char *e = getenv("CTX_G144_PRIO"); prio = e ? atoi(e) : 0; }
-    a.prio = prio;
     a.stage_epi = stg && form != 0 && a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0);
     static bool attr[16] = {};
     auto go = [&](auto kern, int which, int threads, int ns) {

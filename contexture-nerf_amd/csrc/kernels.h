@@ -29,7 +29,6 @@ struct GemmArgs {
                            // steady-state K loop (CTX_GEMM_STEADY=0, the A/B switch of gemm.hip's branch-free loop)
     int tile, use8;        // plan: tile id of gemm.hip (-1 = heuristic); use8: -1 heuristic, 0 gemm.hip, 1 gemm8.hip, 2 / 3 conv_halo.hip (128 / 64 features), 4 / 5 gemm144.hip (6 / 15 waves)
     int stage_epi;         // 1: epilogue staged through LDS (whole-line stores / residual reads)
-    int prio;              // experiment (CTX_G144_PRIO): wave priority scheme of k_gemm144's pipelined form (0 none)
     int mfast;             // 1: consecutive workgroups walk M first (share the weight panel in their XCD's L2)
 };
 
