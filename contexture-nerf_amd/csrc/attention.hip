@@ -50,10 +50,15 @@ __device__ __forceinline__ f16x4 at_tr16(const f16 *p)
     at_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4 *)p);
     return __builtin_bit_cast(f16x4, v);
 }
-template <bool MASK>
+struct AtNoIssue { __device__ __forceinline__ void operator()(int) const {} };
+// NISSUE > 0: `iss(i)` launches DMA piece i of a later tile right behind the i-th QK MFMA.  The four waves of a workgroup leave the
+// tile's barrier together, and 16 KB of global_load_lds issued in one burst queue at the CU's one vector-memory port: timestamps
+// taken inside the loop (s_memtime around each section, round 3) showed ~10 % of a wave's tile period stalled at the issue of
+// its 4 pieces.
+template <bool MASK, int NISSUE = 0, class Issue = AtNoIssue>
 __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 *__restrict__ Vs, int k0, int Skv, int r, int h,
                                           int swz, int vlane, int vfq, float c, const f16x8 (&qf)[4], f32x16 (&o)[2], f32x16 &ls,
-                                          float &m_run)
+                                          float &m_run, Issue iss = Issue())
 {
     f32x16 s[2];
 #pragma unroll
@@ -65,6 +70,7 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
         for (int ks = 0; ks < 4; ++ks) {
             f16x8 kf = *(const f16x8 *)(kr + ((2 * ks + h) ^ swz) * 8);
             s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+            if (kb * 4 + ks < NISSUE) iss(kb * 4 + ks);
         }
     }
     if (MASK) {
@@ -76,15 +82,27 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
                 if (key >= Skv) s[kb][q] = -INFINITY;
             }
     }
-    float mx = fmaxf(s[0][0], s[1][0]);
+    // 32 scores -> three-input maxima in two chains (v_max3_f32), then the other half's lane
+    float mxa = fmaxf(s[0][0], s[0][1]), mxb = fmaxf(s[1][0], s[1][1]);
 #pragma unroll
-    for (int q = 1; q < 16; ++q) mx = fmaxf(mx, fmaxf(s[0][q], s[1][q]));
+    for (int q = 2; q < 16; q += 2) {
+        mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, s[0][q]), s[0][q + 1]);
+        mxb = __builtin_fmaxf(__builtin_fmaxf(mxb, s[1][q]), s[1][q + 1]);
+    }
+    float mx = fmaxf(mxa, mxb);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
     float m_new = fmaxf(m_run, mx);
+    // s * c - m_new two scores per instruction (v_pk_fma_f32: the same fused operation per element), then the exponentials
+    typedef float at_f2 __attribute__((ext_vector_type(2)));
+    const at_f2 c2 = {c, c}, nm2 = {-m_new, -m_new};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s[kb][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][q], c, -m_new));
+        for (int q = 0; q < 16; q += 2) {
+            const at_f2 t = __builtin_elementwise_fma((at_f2){s[kb][q], s[kb][q + 1]}, c2, nm2);
+            s[kb][q] = __builtin_amdgcn_exp2f(t[0]);
+            s[kb][q + 1] = __builtin_amdgcn_exp2f(t[1]);
+        }
     // rescale only when some row's max moved (wave-uniform branch).  The multiplies are inline asm with tied operands:
     // written as C++ the compiler multiplies out of place and then copies all 48 accumulator registers on the
     // fall-through path of every tile, which costs more than multiplying unconditionally.
@@ -120,7 +138,7 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
 
 // NW waves per workgroup (32 queries each): 4 = 128 queries, 8 = 256 queries per staged K/V tile (half the L2 -> LDS bytes per
 // FLOP: the staging path is this chip's scarce resource, ~28 B/clk per CU, and three 4-wave workgroups per CU ask ~20 of it)
-template <int AT_NS, int NW>
+template <int AT_NS, int NW, bool SPREAD = true>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) f16 ring[AT_NS * 2 * 64 * 64];    // per stage: K [64][64] then V^T [64][64]
@@ -182,6 +200,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(Attn
         }
         ++issued;
     };
+    // one piece of tile `issued` (idx < PI: K piece idx, else V piece idx - PI); the caller bumps `issued` after the last one
+    auto issue_piece = [&](int buf, int idx) {
+        f16 *Ks = ring + buf * (2 * 64 * 64);
+        f16 *Vs = Ks + 64 * 64;
+        const int k0 = issued * AT_KB;
+        const int i = idx < PI ? idx : idx - PI;
+        const f16 *&gp = idx < PI ? kp[i] : vp[i];
+        const f16 *src = (k0 + krow[i] < a.Skv) ? gp : g_attn_zero;
+        __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)((idx < PI ? Ks : Vs) + (wave + NW * i) * 512), 16, 0, 0);
+        gp += (size_t)AT_KB * a.kv_stride;
+    };
 #pragma unroll
     for (int p = 0; p < AT_NS - 1; ++p)
         if (p < ntiles) issue(p);
@@ -202,9 +231,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(Attn
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AT_NS - 2) * G) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         ctx_barrier();
-        issue(slot == 0 ? AT_NS - 1 : slot - 1);
+        const int ibuf = slot == 0 ? AT_NS - 1 : slot - 1;
         const f16 *Ks = ring + slot * (2 * 64 * 64);
-        attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
+        if (SPREAD) {
+            attn_tile<false, G>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run, [&](int idx) { issue_piece(ibuf, idx); });
+            ++issued;
+        } else {
+            issue(ibuf);
+            attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
+        }
         slot = slot + 1 == AT_NS ? 0 : slot + 1;
     }
     for (; t < nfull; ++t) {
@@ -255,8 +290,10 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, 
     // x 10 heads, 411 vs 371 us at 9216 x 5 — so only the mid-size self-attention takes them (CTX_ATTN_NW8: 0 never, 1 always)
     if (nw8 < 0) { const char *e = getenv("CTX_ATTN_NW8"); nw8 = e ? atoi(e) : -1; }
     const bool w8 = nw8 == 1 || (nw8 < 0 && Sq >= 1024 && Sq < 4096 && Skv >= 1024);
-    auto kern = w8 ? (ns == 2 ? k_attention_dma<2, 8> : (ns == 4 ? k_attention_dma<4, 8> : k_attention_dma<3, 8>))
-                   : (ns == 2 ? k_attention_dma<2, 4> : (ns == 4 ? k_attention_dma<4, 4> : k_attention_dma<3, 4>));
+    static int spread = -1;             // CTX_ATTN_SPREAD=0: all DMA pieces of a tile right after the barrier (the A/B switch)
+    if (spread < 0) { const char *e = getenv("CTX_ATTN_SPREAD"); spread = e ? atoi(e) : 1; }
+    auto kern = w8 ? (ns == 2 ? k_attention_dma<2, 8> : (ns == 4 ? k_attention_dma<4, 8> : (spread ? k_attention_dma<3, 8> : k_attention_dma<3, 8, false>)))
+                   : (ns == 2 ? k_attention_dma<2, 4> : (ns == 4 ? k_attention_dma<4, 4> : (spread ? k_attention_dma<3, 4> : k_attention_dma<3, 4, false>)));
     const int nthr = w8 ? 512 : 256, qpw = w8 ? 256 : 128;
     static int dbg = -1;
     if (dbg < 0) {
