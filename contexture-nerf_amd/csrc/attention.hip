@@ -25,6 +25,7 @@ struct AttnArgs {
     int Sq, Skv, heads;
     int q_stride, kv_stride, o_stride;
     float scale_log2e;
+    float lazy;            // log2 units a row's maximum may run ahead of the subtracted one before the accumulators are rescaled (0: never)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -58,7 +59,7 @@ struct AtNoIssue { __device__ __forceinline__ void operator()(int) const {} };
 template <bool MASK, int NISSUE = 0, class Issue = AtNoIssue>
 __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 *__restrict__ Vs, int k0, int Skv, int r, int h,
                                           int swz, int vlane, int vfq, float c, const f16x8 (&qf)[4], f32x16 (&o)[2], f32x16 &ls,
-                                          float &m_run, Issue iss = Issue())
+                                          float &m_run, float lazy, Issue iss = Issue())
 {
     f32x16 s[2];
 #pragma unroll
@@ -91,7 +92,12 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
     }
     float mx = fmaxf(mxa, mxb);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
-    float m_new = fmaxf(m_run, mx);
+    // The subtracted maximum is any per-row constant: it follows the true running maximum only when some row of the wave has moved by
+    // more than `lazy` (P then stays <= 2^lazy, exact in fp16's range), which skips most of the 33-multiply rescales of O and l
+    // (lazy = 0: every change, the textbook recurrence; first tile: m_run = -inf always moves)
+    const float m_cand = fmaxf(m_run, mx);
+    const bool move = __any(m_cand > m_run + lazy);
+    const float m_new = move ? m_cand : m_run;
     // s * c - m_new two scores per instruction (v_pk_fma_f32: the same fused operation per element), then the exponentials
     typedef float at_f2 __attribute__((ext_vector_type(2)));
     const at_f2 c2 = {c, c}, nm2 = {-m_new, -m_new};
@@ -106,7 +112,7 @@ __device__ __forceinline__ void attn_tile(const f16 *__restrict__ Ks, const f16 
     // rescale only when some row's max moved (wave-uniform branch).  The multiplies are inline asm with tied operands:
     // written as C++ the compiler multiplies out of place and then copies all 48 accumulator registers on the
     // fall-through path of every tile, which costs more than multiplying unconditionally.
-    if (__any(m_new != m_run)) {
+    if (move) {
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 on the first tile (m_run = -inf)
         // s_nop: alpha comes straight from v_exp_f32 (transcendental -> VALU use needs a wait state hipcc cannot see into)
         asm volatile("s_nop 1\n\tv_mul_f32 %0, %0, %1" : "+v"(ls[0]) : "v"(alpha));
@@ -234,11 +240,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(Attn
         const int ibuf = slot == 0 ? AT_NS - 1 : slot - 1;
         const f16 *Ks = ring + slot * (2 * 64 * 64);
         if (SPREAD) {
-            attn_tile<false, G>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run, [&](int idx) { issue_piece(ibuf, idx); });
+            attn_tile<false, G>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run, a.lazy, [&](int idx) { issue_piece(ibuf, idx); });
             ++issued;
         } else {
             issue(ibuf);
-            attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
+            attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run, a.lazy);
         }
         slot = slot + 1 == AT_NS ? 0 : slot + 1;
     }
@@ -253,14 +259,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_attention_dma(Attn
         ctx_barrier();
         if (issued < ntiles) issue(slot == 0 ? AT_NS - 1 : slot - 1);          // the slot tile t-1 used
         const f16 *Ks = ring + slot * (2 * 64 * 64);
-        attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
+        attn_tile<false>(Ks, Ks + 64 * 64, t * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run, a.lazy);
         slot = slot + 1 == AT_NS ? 0 : slot + 1;
     }
     if (nfull < ntiles) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ctx_barrier();
         const f16 *Ks = ring + slot * (2 * 64 * 64);
-        attn_tile<true>(Ks, Ks + 64 * 64, nfull * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run);
+        attn_tile<true>(Ks, Ks + 64 * 64, nfull * AT_KB, a.Skv, r, h, swz, vlane, vfq, c, qf, o, ls, m_run, a.lazy);
     }
     if (qok) {
         float inv = 1.0f / ls[0];
@@ -284,6 +290,9 @@ int ctx_attention_core(const f16 *Q, const f16 *K, const f16 *V, int B, int Sq, 
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.Sq = Sq; a.Skv = Skv; a.heads = heads;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
+    static float lazy = -1.f;           // CTX_ATTN_LAZY: threshold in log2 units (default 8 = a factor 256; 0 = rescale on every change)
+    if (lazy < 0.f) { const char *e = getenv("CTX_ATTN_LAZY"); lazy = e ? (float)atof(e) : 8.0f; if (!(lazy >= 0.f && lazy <= 12.f)) lazy = 8.0f; }
+    a.lazy = lazy;
     static int ns = -1, nw8 = -1;
     if (ns < 0) { const char *e = getenv("CTX_ATTN_NS"); ns = e ? atoi(e) : 3; }
     // 8-wave workgroups (two per CU at 128 VGPRs) measured against three 4-wave ones (148 VGPRs): 72 vs 77 us at 2304 tokens
