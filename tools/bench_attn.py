@@ -6,7 +6,7 @@ import torch
 from contexture_nerf_amd import _lib as L
 lib = L.load(); dev = torch.device('cuda:0')
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-shapes = [(2, 9216, 9216, 5), (2, 2304, 2304, 10), (2, 576, 576, 20), (2, 9216, 77, 5), (2, 8192, 8192, 12)]   # the last: 6144 waves = whole rounds at 2 and at 3 waves per SIMD
+shapes = [(2, 9216, 9216, 5), (2, 2304, 2304, 10), (2, 576, 576, 20), (2, 9216, 77, 5), (2, 8192, 8192, 12), (12, 9216, 9216, 5), (4, 9216, 9216, 5), (6, 9216, 9216, 5), (1, 9216, 9216, 5), (2, 9216, 9216, 10), (2, 4608, 9216, 5)]   # the last: 6144 waves = whole rounds at 2 and at 3 waves per SIMD
 if len(sys.argv) > 2:
     shapes = [shapes[int(i)] for i in sys.argv[2].split(',')]
 for (B, S, Skv, heads) in shapes:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One UNet evaluation over V views batched (batch 2V, CFG pairs) against V evaluations of batch 2: milliseconds per view-step.
-Usage: python tools/bench_batched.py [latent] [iters]"""
+Usage: python tools/bench_batched.py [latent] [iters] [views,views,...]"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,8 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device('cuda:0')
 net = UNet2DConditionModel(device=dev, seed=0)
 g = torch.Generator(device=dev).manual_seed(0)
-for V in (1, 2, 3, 6):
+views = tuple(int(v) for v in sys.argv[3].split(',')) if len(sys.argv) > 3 else (1, 2, 3, 6)
+for V in views:
     x = torch.randn(2 * V, 5, S, S, generator=g, device=dev)
     ctx = torch.randn(2 * V, 77, 1024, generator=g, device=dev)
     for _ in range(2):
