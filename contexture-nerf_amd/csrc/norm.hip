@@ -37,7 +37,9 @@ __device__ __forceinline__ F8 ld8(const void *base, size_t elem)
 #define GN_MAX_SPLITS 128
 #define GN_MAX_C 4096
 #define GN_U 4
-#define GN_AU 4
+#define GN_AU 12
+#define GN_AU32 6
+#define GN_FOLD 4
 
 template <bool X32>
 __global__ __launch_bounds__(1024) void k_gn_stats(const void *__restrict__ x, int HW, int C, int G, int NS, int PL,
@@ -107,41 +109,59 @@ __global__ __launch_bounds__(1024) void k_gn_stats(const void *__restrict__ x, i
     }
 }
 
+// 8 consecutive channels as they lie in memory (converted at use: 12 chunks in flight cost 48 VGPRs as fp16, 96 as floats)
+template <bool X32> struct Raw8;
+template <> struct Raw8<false> {
+    f16x8 a;
+    __device__ __forceinline__ float get(int j) const { return (float)a[j]; }
+};
+template <> struct Raw8<true> {
+    f32x4 a, b;
+    __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+};
 template <bool X32>
-__global__ __launch_bounds__(256) void k_gn_apply(const void *__restrict__ x, const float *__restrict__ part,
-                                                  const f16 *__restrict__ gamma, const f16 *__restrict__ beta, int HW, int C,
-                                                  int G, int NS, float eps, int silu, f16 *__restrict__ y)
+__device__ __forceinline__ Raw8<X32> ldraw(const void *base, size_t elem)
 {
-    extern __shared__ float s_ab[];          // [2][C]
+    Raw8<X32> r;
+    if constexpr (X32) { r.a = *(const f32x4 *)((const float *)base + elem); r.b = *(const f32x4 *)((const float *)base + elem + 4); }
+    else r.a = *(const f16x8 *)((const f16 *)base + elem);
+    return r;
+}
+
+// Pass 2.  Block = c8n chunk columns x PL pixel lanes (>= 256 threads); a thread owns ONE column of 8 channels, so its scale and shift
+// live in 16 registers, and walks AU pixels of the block's contiguous pixel run, all AU 16-byte loads in flight before anything else
+// (the fold of the split partials happens under them).  The form before this one let a thread's column vary with the chunk and
+// fetched scale / shift from an LDS table: four ds_read_b128 per chunk at a 32-byte lane stride, i.e. bank-conflicted LDS reads of
+// four times the payload — tools/probes/stream_probe.hip: a copy-shaped kernel goes from 3.9 to 8.8 us on 12 MB with exactly that
+// table read added, and stays at 4.3 with the values in registers (SiLU and the index arithmetic cost nothing measurable).
+template <bool X32>
+__global__ __launch_bounds__(512) void k_gn_apply(const void *__restrict__ x, const float *__restrict__ part,
+                                                  const f16 *__restrict__ gamma, const f16 *__restrict__ beta, int HW, int C,
+                                                  int G, int NS, int PL, float eps, int silu, f16 *__restrict__ y)
+{
+    constexpr int AU = X32 ? GN_AU32 : GN_AU;
     __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
     const int b = blockIdx.y;
     const int c8n = C / 8;
-    const size_t xb = (size_t)b * HW * C;
-    f16 *yb = y + (size_t)b * HW * C;
-    const unsigned total = (unsigned)HW * (unsigned)c8n;
-    // a block owns a contiguous run of 16-byte chunks and walks it in batches of GN_AU x 256
-    const unsigned per = ((total + gridDim.x - 1) / gridDim.x + 255u) & ~255u;
-    const unsigned beg = blockIdx.x * per, end = min(total, beg + per);
-    F8 v[GN_AU];
+    const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
+    const int p0 = blockIdx.x * (PL * AU);
+    const size_t xb = (size_t)b * HW * C + c8 * 8;
+    f16 *yb = y + (size_t)b * HW * C + c8 * 8;
+    Raw8<X32> v[AU];
 #pragma unroll
-    for (int u = 0; u < GN_AU; ++u)                                         // first batch: in flight during the fold below
-        v[u] = ld8<X32>(x, xb + (size_t)min(beg + 256u * u + threadIdx.x, total - 1u) * 8);
-    // gamma / beta go to LDS now (their latency overlaps the partial loads below instead of following the barrier)
-    for (int c = threadIdx.x; c < C; c += 256) {
-        s_ab[c] = (float)gamma[c];
-        s_ab[C + c] = (float)beta[c];
-    }
-    {
+    for (int u = 0; u < AU; ++u) v[u] = ldraw<X32>(x, xb + (size_t)min(p0 + u * PL + pl, HW - 1) * C);    // unconditional (clamped)
+    const f16x8 ga = *(const f16x8 *)(gamma + c8 * 8), be = *(const f16x8 *)(beta + c8 * 8);
+    if (threadIdx.x < 256) {
         const int lpg = 256 / G;
         const int g = threadIdx.x / lpg, l = threadIdx.x % lpg;
         float s = 0.f, q = 0.f;
-        for (int k0 = 0; k0 < NS; k0 += 4 * lpg) {                          // 4 independent loads per trip, fixed order
-            float2 pv[4];
+        for (int k0 = 0; k0 < NS; k0 += GN_FOLD * lpg) {                    // GN_FOLD independent loads per trip, fixed order
+            float2 pv[GN_FOLD];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < GN_FOLD; ++k)
                 pv[k] = *(const float2 *)(part + (((size_t)b * NS + min(k0 + k * lpg + l, NS - 1)) * G + g) * 2);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < GN_FOLD; ++k)
                 if (k0 + k * lpg + l < NS) { s += pv[k].x; q += pv[k].y; }
         }
         for (int o = lpg >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
@@ -155,43 +175,25 @@ __global__ __launch_bounds__(256) void k_gn_apply(const void *__restrict__ x, co
     }
     __syncthreads();
     const int cg = C / G;
-    for (int c = threadIdx.x; c < C; c += 256) {                             // same thread wrote these two cells above
-        int gg = c / cg;
-        float sa = s_rstd[gg] * s_ab[c];
-        s_ab[C + c] = s_ab[C + c] - s_mean[gg] * sa;
-        s_ab[c] = sa;
+    float sa[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int gg = (c8 * 8 + j) / cg;
+        sa[j] = s_rstd[gg] * (float)ga[j];
+        sh[j] = (float)be[j] - s_mean[gg] * sa[j];
     }
-    __syncthreads();
-    for (unsigned i0 = beg; i0 < end; i0 += 256u * GN_AU) {
-        F8 nx[GN_AU];
-        const unsigned n0 = i0 + 256u * GN_AU;
-        if (n0 < end) {
 #pragma unroll
-            for (int u = 0; u < GN_AU; ++u) nx[u] = ld8<X32>(x, xb + (size_t)min(n0 + 256u * u + threadIdx.x, total - 1u) * 8);
-        }
+    for (int u = 0; u < AU; ++u) {
+        const int p = p0 + u * PL + pl;
+        if (p < HW) {
+            f16x8 o;
 #pragma unroll
-        for (int u = 0; u < GN_AU; ++u) {
-            const unsigned i = i0 + 256u * u + threadIdx.x;
-            if (i < end) {
-                int c0 = (int)(i % (unsigned)c8n) * 8;
-                f32x4 a0 = *(const f32x4 *)(s_ab + c0), a1 = *(const f32x4 *)(s_ab + c0 + 4);
-                f32x4 b0 = *(const f32x4 *)(s_ab + C + c0), b1 = *(const f32x4 *)(s_ab + C + c0 + 4);
-                float f[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { f[j] = v[u].v[j] * a0[j] + b0[j]; f[4 + j] = v[u].v[4 + j] * a1[j] + b1[j]; }
-                f16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float t = f[j];
-                    if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
-                    o[j] = (f16)t;
-                }
-                *(f16x8 *)(yb + (size_t)i * 8) = o;
+            for (int j = 0; j < 8; ++j) {
+                float t = v[u].get(j) * sa[j] + sh[j];
+                if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+                o[j] = (f16)t;
             }
-        }
-        if (n0 < end) {
-#pragma unroll
-            for (int u = 0; u < GN_AU; ++u) v[u] = nx[u];
+            *(f16x8 *)(yb + (size_t)p * C) = o;
         }
     }
 }
@@ -204,30 +206,26 @@ __global__ __launch_bounds__(256) void k_gn_apply(const void *__restrict__ x, co
 #define GN_FU 12
 template <bool X32>
 __global__ __launch_bounds__(GN_FT) void k_gn_fused(const void *__restrict__ x, const f16 *__restrict__ gamma,
-                                                    const f16 *__restrict__ beta, int HW, int C, int G, float eps, int silu,
+                                                    const f16 *__restrict__ beta, int HW, int C, int G, int PLF, float eps, int silu,
                                                     f16 *__restrict__ y)
 {
+    // threads = cpg chunk columns x PLF pixel lanes: a thread keeps one column, so gamma / beta are 16 registers (an LDS table read per
+    // chunk at a 32-byte lane stride is bank-conflicted and was the slowest part of the apply kernels: tools/probes/stream_probe.hip)
     __shared__ float s_red[2][GN_FT / 64];
-    __shared__ float s_gb[2][GN_MAX_C / 16];          // this group's gamma, beta (cg <= 256 channels)
     const int g = blockIdx.x, b = blockIdx.y;
     const int cg = C / G, cpg = cg / 8;                // chunks per pixel in this group
-    const int total = HW * cpg;
-    const size_t xb = (size_t)b * HW * C + g * cg;
-    f16 *yb = y + (size_t)b * HW * C + g * cg;
-    for (int c = threadIdx.x; c < cg; c += GN_FT) { s_gb[0][c] = (float)gamma[g * cg + c]; s_gb[1][c] = (float)beta[g * cg + c]; }
+    const int c = threadIdx.x % cpg, pl = threadIdx.x / cpg;
+    const bool act = pl < PLF;                         // blockDim.x is rounded up to whole waves
+    const size_t xb = (size_t)b * HW * C + g * cg + c * 8;
+    f16 *yb = y + (size_t)b * HW * C + g * cg + c * 8;
+    const f16x8 ga = *(const f16x8 *)(gamma + g * cg + c * 8), be = *(const f16x8 *)(beta + g * cg + c * 8);
     F8 v[GN_FU];
-    int off[GN_FU];
 #pragma unroll
-    for (int u = 0; u < GN_FU; ++u) {
-        const int i = min((int)threadIdx.x + GN_FT * u, total - 1);
-        const int p = i / cpg, c = i - p * cpg;
-        off[u] = p * C + c * 8;
-        v[u] = ld8<X32>(x, xb + off[u]);               // unconditional (clamped), all in flight
-    }
+    for (int u = 0; u < GN_FU; ++u) v[u] = ld8<X32>(x, xb + (size_t)min(pl + PLF * u, HW - 1) * C);     // unconditional (clamped), all in flight
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int u = 0; u < GN_FU; ++u)
-        if ((int)threadIdx.x + GN_FT * u < total) {
+        if (act && pl + PLF * u < HW) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { float f = v[u].v[j]; s += f; q += f * f; }
         }
@@ -236,24 +234,26 @@ __global__ __launch_bounds__(GN_FT) void k_gn_fused(const void *__restrict__ x, 
     if ((threadIdx.x & 63) == 0) { s_red[0][wave] = s; s_red[1][wave] = q; }
     __syncthreads();
     float ss = 0.f, qq = 0.f;
-#pragma unroll
-    for (int w = 0; w < GN_FT / 64; ++w) { ss += s_red[0][w]; qq += s_red[1][w]; }
+    const int nw = ((int)blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) { ss += s_red[0][w]; qq += s_red[1][w]; }
     const float n = (float)HW * (float)cg;
     const float mean = ss / n;
     const float rstd = rsqrtf(fmaxf(qq / n - mean * mean, 0.f) + eps);
+    float sa[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sa[j] = rstd * (float)ga[j]; sh[j] = (float)be[j] - mean * sa[j]; }
 #pragma unroll
     for (int u = 0; u < GN_FU; ++u) {
-        const int i = (int)threadIdx.x + GN_FT * u;
-        if (i < total) {
-            const int c0 = (i % cpg) * 8;
+        const int p = pl + PLF * u;
+        if (act && p < HW) {
             f16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float t = (v[u].v[j] - mean) * rstd * s_gb[0][c0 + j] + s_gb[1][c0 + j];
+                float t = v[u].v[j] * sa[j] + sh[j];
                 if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
                 o[j] = (f16)t;
             }
-            *(f16x8 *)(yb + off[u]) = o;
+            *(f16x8 *)(yb + (size_t)p * C) = o;
         }
     }
 }
@@ -282,9 +282,12 @@ int ctx_groupnorm_any(const void *x, int x32, const void *gamma, const void *bet
         static int fuse = -1;
         if (fuse < 0) { const char *e = getenv("CTX_GN_FUSED"); fuse = e ? atoi(e) : 1; }
         const int cg = C / groups;
-        if (fuse && cg % 8 == 0 && cg <= GN_MAX_C / 16 && (int64_t)HW * (cg / 8) <= GN_FT * GN_FU) {
-            if (x32) hipLaunchKernelGGL(k_gn_fused<true>, dim3(groups, B), dim3(GN_FT), 0, s, x, (const f16 *)gamma, (const f16 *)beta, HW, C, groups, eps, silu, (f16 *)y);
-            else hipLaunchKernelGGL(k_gn_fused<false>, dim3(groups, B), dim3(GN_FT), 0, s, x, (const f16 *)gamma, (const f16 *)beta, HW, C, groups, eps, silu, (f16 *)y);
+        const int cpg = cg / 8;
+        const int plf = cg % 8 == 0 ? GN_FT / cpg : 0;                  // pixel lanes of the one-kernel form
+        if (fuse && cg % 8 == 0 && cpg <= GN_FT && (HW + plf - 1) / plf <= GN_FU) {
+            const int thr = (cpg * plf + 63) / 64 * 64;
+            if (x32) hipLaunchKernelGGL(k_gn_fused<true>, dim3(groups, B), dim3(thr), 0, s, x, (const f16 *)gamma, (const f16 *)beta, HW, C, groups, plf, eps, silu, (f16 *)y);
+            else hipLaunchKernelGGL(k_gn_fused<false>, dim3(groups, B), dim3(thr), 0, s, x, (const f16 *)gamma, (const f16 *)beta, HW, C, groups, plf, eps, silu, (f16 *)y);
             CTX_CHECK_LAUNCH("groupnorm");
             return CTX_OK;
         }
@@ -316,14 +319,16 @@ int ctx_groupnorm_any(const void *x, int x32, const void *gamma, const void *bet
     else hipLaunchKernelGGL(k_gn_stats<false>, dim3(NS, B), dim3(threads), lds, s, x, HW, C, groups, NS, PL, part);
     size_t total = (size_t)HW * c8n;
     // fat blocks (the per-block fold of the split partials is amortised), at least one batch each
-    int nb = (int)((total + 256 * GN_AU - 1) / (256 * GN_AU));
-    static const int cap_env = [] { const char *e = getenv("CTX_GN_APPLY_CAP"); return e ? atoi(e) : 0; }();
-    const int cap = cap_env > 0 ? cap_env : (B >= 2 ? 128 : 256);   // ~one block per CU: the per-block fold of the partials is not free
-    if (nb > cap) nb = cap;
-    if (x32) hipLaunchKernelGGL(k_gn_apply<true>, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, x, part, (const f16 *)gamma,
-                                (const f16 *)beta, HW, C, groups, NS, eps, silu, (f16 *)y);
-    else hipLaunchKernelGGL(k_gn_apply<false>, dim3(nb, B), dim3(256), (size_t)2 * C * sizeof(float), s, x, part, (const f16 *)gamma,
-                            (const f16 *)beta, HW, C, groups, NS, eps, silu, (f16 *)y);
+    {
+        const int au = x32 ? GN_AU32 : GN_AU;
+        const int apl = (256 + c8n - 1) / c8n;                      // pixel lanes: >= 256 threads (the fold uses 256), <= 512
+        const int athreads = c8n * apl;
+        const int nb = (HW + apl * au - 1) / (apl * au);
+        if (x32) hipLaunchKernelGGL(k_gn_apply<true>, dim3(nb, B), dim3(athreads), 0, s, x, part, (const f16 *)gamma, (const f16 *)beta, HW, C,
+                                    groups, NS, apl, eps, silu, (f16 *)y);
+        else hipLaunchKernelGGL(k_gn_apply<false>, dim3(nb, B), dim3(athreads), 0, s, x, part, (const f16 *)gamma, (const f16 *)beta, HW, C,
+                                groups, NS, apl, eps, silu, (f16 *)y);
+    }
     CTX_CHECK_LAUNCH("groupnorm");
     return CTX_OK;
 }
