@@ -39,7 +39,7 @@ __device__ __forceinline__ F8 ld8(const void *base, size_t elem)
 #define GN_U 4
 #define GN_AU 12
 #define GN_AU32 6
-#define GN_FOLD 4
+#define GN_FOLD 8
 
 template <bool X32>
 __global__ __launch_bounds__(1024) void k_gn_stats(const void *__restrict__ x, int HW, int C, int G, int NS, int PL,
