@@ -152,8 +152,9 @@ __global__ __launch_bounds__(512) void k_gn_apply(const void *__restrict__ x, co
     for (int u = 0; u < AU; ++u) v[u] = ldraw<X32>(x, xb + (size_t)min(p0 + u * PL + pl, HW - 1) * C);    // unconditional (clamped)
     const f16x8 ga = *(const f16x8 *)(gamma + c8 * 8), be = *(const f16x8 *)(beta + c8 * 8);
     if (threadIdx.x < 256) {
-        const int lpg = 256 / G;
-        const int g = threadIdx.x / lpg, l = threadIdx.x % lpg;
+        const int lpg = min(256 / G, 64);                                   // lanes per group: a power of two inside one wave (G < 4: idle lanes)
+        const int gi = threadIdx.x / lpg, l = threadIdx.x % lpg;
+        const int g = min(gi, G - 1);
         float s = 0.f, q = 0.f;
         for (int k0 = 0; k0 < NS; k0 += GN_FOLD * lpg) {                    // GN_FOLD independent loads per trip, fixed order
             float2 pv[GN_FOLD];
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(512) void k_gn_apply(const void *__restrict__ x, co
                 if (k0 + k * lpg + l < NS) { s += pv[k].x; q += pv[k].y; }
         }
         for (int o = lpg >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if (l == 0) {
+        if (l == 0 && gi < G) {
             float n = (float)HW * (float)(C / G);
             float mean = s / n;
             float var = fmaxf(q / n - mean * mean, 0.f);

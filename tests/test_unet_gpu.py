@@ -284,7 +284,12 @@ def test_tuned_plans_against_torch(dev):
 
 @pytest.mark.parametrize("B,HW,Cc,G,silu", [(2, 256, 64, 32, 1), (2, 1024, 320, 32, 1), (1, 144, 1280, 32, 0),
                                             (2, 400, 2560, 32, 1), (2, 576, 1920, 32, 1), (2, 100, 960, 32, 0),
-                                            (2, 576, 1280, 32, 1), (2, 1229, 1280, 32, 0)])
+                                            (2, 576, 1280, 32, 1), (2, 1229, 1280, 32, 0),
+                                            # r3 thread mappings (a thread keeps one 8-channel column): batch 12, pixel counts that are no
+                                            # multiple of lanes x chunks, column counts that do not divide 256, 8 channels, 4 groups, C = 4096
+                                            (12, 2304, 640, 32, 1), (12, 576, 1280, 32, 1), (3, 1237, 320, 32, 1), (1, 9216, 960, 32, 1),
+                                            (2, 77, 8, 1, 0), (2, 513, 96, 4, 1), (1, 301, 4096, 32, 0), (5, 37, 2560, 32, 1),
+                                            (2, 3001, 24, 1, 1), (1, 2304, 1920, 32, 1)])
 def test_groupnorm(dev, B, HW, Cc, G, silu):
     L, lib = _lib()
     g = torch.Generator().manual_seed(Cc)
