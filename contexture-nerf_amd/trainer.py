@@ -5,7 +5,7 @@ UV back-projection as a scatter into the atlas, RCCL all-reduce of the atlas).
 
 Also here: `project_back` under the reference's call contract (trainer.py:1076-1090; it has no body there, so the
 direct UV-scatter form `project_back_scatter` stands in, parity unpinned), the eval renders (`eval_render`,
-`evaluate`, `full_eval`, :913-968, 1119-1157) and the mesh export.  Not built: wandb/loguru logging, the mp4 mux.
+`evaluate`, `full_eval`, :913-968, 1119-1157) and the mesh export.  Not built: wandb/loguru logging; the mp4 of `full_eval` is a Motion-JPEG AVI (video.py: no H.264 encoder offline).
 """
 import math
 import os
@@ -247,17 +247,21 @@ class ConTEXTure:
     @torch.no_grad()
     def evaluate(self, dataloader, save_path, save_as_video=False):
         """trainer.py:913-952: one rgb frame (+ normal map) per eval view and the texture atlas, under the reference's file names.
-        `save_as_video`: the reference muxes an mp4 with imageio (absent offline); the frames are written as numbered JPGs."""
+        `save_as_video`: the reference muxes `eval:constructed_video:all_rendered_rgb_<seed>.mp4` with imageio / ffmpeg (neither is
+        importable offline); the same frames at the same 25 fps go into a Motion-JPEG `.avi` of that name (video.write_mjpeg_avi), and the
+        numbered JPGs are kept beside it."""
         import os
         import numpy as np
         from PIL import Image
         save_path = str(save_path)
         os.makedirs(save_path, exist_ok=True)
         to8 = lambda t: (t.detach().cpu().numpy() * 255).astype(np.uint8)
-        n, textures = 0, None
+        n, textures, all_preds = 0, None, []
         for i, data in enumerate(dataloader):
             preds, textures, depths, normals = self.eval_render(data)
             tag = 'video_frame' if save_as_video else 'rendered_image'
+            if save_as_video:
+                all_preds.append(to8(preds[0]))
             Image.fromarray(to8(preds[0])).save(os.path.join(save_path, f"eval:{tag}:{i:04d}_rgb.jpg"))
             if not save_as_video:
                 nm = to8(normals[0, 0])
@@ -267,6 +271,9 @@ class ConTEXTure:
             n += 1
         if textures is not None:
             Image.fromarray(to8(textures[0])).save(os.path.join(save_path, "eval:texture_atlas:texture.png"))
+        if save_as_video and all_preds:
+            from .video import write_mjpeg_avi
+            write_mjpeg_avi(os.path.join(save_path, f"eval:constructed_video:all_rendered_rgb_{self.cfg.optim.seed}.avi"), all_preds, fps=25)
         return n
 
     def full_eval(self, output_dir=None, size=None):

@@ -461,6 +461,9 @@ def test_paint_zero123plus_loop_and_eval(dev, tmp_path):
     out = cfg.log.exp_dir / 'results'
     assert n == 5 and len([f for f in os.listdir(out) if f.endswith('_rgb.jpg')]) == 5
     assert os.path.exists(out / "eval:texture_atlas:texture.png") and os.path.exists(cfg.log.exp_dir / 'mesh' / 'mesh.obj')
+    from contexture_nerf_amd.video import read_mjpeg_avi
+    fps, frames = read_mjpeg_avi(out / f"eval:constructed_video:all_rendered_rgb_{cfg.optim.seed}.avi")      # the reference's mp4, as Motion-JPEG
+    assert fps == 25 and len(frames) == 5 and frames[0].shape[2] == 3
     # should_project_back (the reference's default): the painted view lands in the running atlas and the fitted render returns
     rgb, obj = tr.paint_viewpoint(tr.train_views[1])
     assert tr.fitted_pred_rgb.shape == rgb.shape and float(tr.atlas_contrib[3].sum()) > 0
