@@ -400,6 +400,59 @@ __global__ __launch_bounds__(256) void k_layernorm(const void *__restrict__ x, c
     }
 }
 
+// 8 lanes per row, KC 16-byte chunks per lane (C = 64 KC): every lane of the wave carries data (the one-wave-per-row form above leaves
+// 24 of 64 lanes idle at C = 320 and 640), a lane's chunks k*8 + s make 128-byte runs with its 7 neighbours, and a wave keeps 8 rows x KC
+// loads in flight.  The 8-lane sums are three DPP adds (quad_perm, quad_perm, row_half_mirror); same two-pass mean / variance and the same
+// rounding points as k_layernorm, another summation order.
+__device__ __forceinline__ float sum8_dpp(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    return v;
+}
+template <int KC>
+__global__ __launch_bounds__(256) void k_layernorm_g8(const f16 *__restrict__ x, const f16 *__restrict__ gamma, const f16 *__restrict__ beta,
+                                                      int64_t rows, float eps, f16 *__restrict__ y)
+{
+    constexpr int C = 64 * KC;
+    const int lane = threadIdx.x & 63, s = lane & 7, rw = lane >> 3;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t row = wave * 8 + rw;
+    const bool live = row < rows;                                   // uniform over the row's 8 lanes
+    const f16 *xr = x + (live ? row : rows - 1) * C + s * 8;
+    f16x8 v[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) v[k] = *(const f16x8 *)(xr + k * 64);
+    f16x8 ga[KC], be[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        ga[k] = *(const f16x8 *)(gamma + k * 64 + s * 8);
+        be[k] = *(const f16x8 *)(beta + k * 64 + s * 8);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (float)v[k][j];
+    const float mean = sum8_dpp(sum) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)v[k][j] - mean; q += d * d; }
+    const float rstd = rsqrtf(sum8_dpp(q) / (float)C + eps);
+    if (!live) return;
+    f16 *yr = y + row * C + s * 8;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)v[k][j] - mean) * rstd * (float)ga[k][j] + (float)be[k][j]);
+        *(f16x8 *)(yr + k * 64) = o;
+    }
+}
+
 extern "C" int32_t ctx_layernorm_f16(const void *x, const void *gamma, const void *beta, int64_t rows, int32_t C, float eps,
                                      void *y, ctx_stream_t stream)
 {
@@ -409,6 +462,21 @@ extern "C" int32_t ctx_layernorm_f16(const void *x, const void *gamma, const voi
 int ctx_layernorm_any(const void *x, int x32, const void *gamma, const void *beta, int64_t rows, int C, float eps, void *y, hipStream_t stream)
 {
     CTX_REQUIRE(x && gamma && beta && y && rows > 0 && C % 8 == 0 && C <= 2048, "layernorm: unsupported rows=%lld C=%d", (long long)rows, C);
+    {
+        // fp16 input, C a multiple of 64 up to 640 (beyond that the one-wave-per-row form fills >= 83 % of its lanes and gamma / beta for 20
+        // chunks per lane would not fit the registers): 8 lanes per row (CTX_LN_G8=0: the one-wave-per-row kernels)
+        static const int g8 = [] { const char *e = getenv("CTX_LN_G8"); return e ? atoi(e) : 1; }();
+        if (g8 && !x32 && C % 64 == 0 && C <= 640 && rows >= 64) {
+            const unsigned nb = (unsigned)cdiv64(cdiv64(rows, 8), 4);
+#define LN_G8(KC_) case KC_: hipLaunchKernelGGL(k_layernorm_g8<KC_>, dim3(nb), dim3(256), 0, stream, (const f16 *)x, (const f16 *)gamma, (const f16 *)beta, rows, eps, (f16 *)y); break
+            switch (C / 64) {
+                LN_G8(1); LN_G8(2); LN_G8(3); LN_G8(4); LN_G8(5); LN_G8(6); LN_G8(7); LN_G8(8); LN_G8(9); LN_G8(10);
+            }
+#undef LN_G8
+            CTX_CHECK_LAUNCH("layernorm");
+            return CTX_OK;
+        }
+    }
     const int kc = (C / 8 + 63) / 64;                          // 16-byte chunks per lane per row
 #define LN_GO(KC_, R_) do { int64_t nb = cdiv64(cdiv64(rows, R_), 4); \
         if (x32) hipLaunchKernelGGL((k_layernorm<KC_, R_, true>), dim3((unsigned)nb), dim3(256), 0, stream, x, \

@@ -310,7 +310,8 @@ def test_groupnorm(dev, B, HW, Cc, G, silu):
 def test_layernorm_geglu(dev):
     L, lib = _lib()
     g = torch.Generator().manual_seed(3)
-    for rows, Cc in [(77, 320), (513, 1280), (9, 64)]:
+    # (rows, C): both kernel families — 8 lanes per row (C % 64 == 0, C <= 640, rows >= 64; ragged last group of 8 rows and of 32) and one wave per row
+    for rows, Cc in [(77, 320), (513, 1280), (9, 64), (18432, 320), (4609, 640), (64, 64), (1001, 448), (129, 576), (300, 1920), (63, 320), (200, 200)]:
         x = (torch.randn(rows, Cc, generator=g) * 3 - 1).half()
         ga = (1 + 0.2 * torch.randn(Cc, generator=g)).half(); be = (0.2 * torch.randn(Cc, generator=g)).half()
         xd, gd, bd = x.to(dev), ga.to(dev), be.to(dev)
