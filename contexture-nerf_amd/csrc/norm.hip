@@ -300,11 +300,14 @@ int ctx_groupnorm_any(const void *x, int x32, const void *gamma, const void *bet
     int threads = c8n * PL;
     int NS = min(GN_MAX_SPLITS, max(1, HW / PL));             // >= one pixel per lane per split
     {
-        // Few, fat splits: a block's fold (two barriers, LDS walks, a shuffle tree) costs the same whatever it summed, and every apply
-        // block re-reads all NS partials of its sample.  ~256 stats blocks in total, 16 .. 48 per sample: at batch 12 (six views in
-        // lockstep) the GroupNorms of one evaluation take 2.5 ms instead of 3.8, at batch 2 0.95 instead of 1.04 (CTX_GN_NS overrides)
+        // Fat splits: a block's fold (two barriers, LDS walks, a shuffle tree) costs the same whatever it summed, and every apply block
+        // re-reads all NS partials of its sample — but a 150 MB VAE tensor at batch 1 still needs all 128 of them to fill the chip.
+        // ~384 KB of the sample per split, at least 64 stats blocks in all (measured, GroupNorm per evaluation: UNet batch 12 3.30 ms at
+        // 128 splits / 2.13 at 16; batch 2 1.01 / 0.94 at 32; the VAE decoder's at 768^2 1.36 ms at 128 / 1.71 at 48).  CTX_GN_NS overrides.
         static const int ns_env = [] { const char *e = getenv("CTX_GN_NS"); return e ? atoi(e) : 0; }();
-        const int want = ns_env > 0 ? ns_env : min(48, max(16, 256 / B));
+        const int64_t sample_bytes = (int64_t)HW * C * (x32 ? 4 : 2);
+        const int by_size = (int)min((int64_t)GN_MAX_SPLITS, sample_bytes / (384 * 1024));
+        const int want = ns_env > 0 ? ns_env : max(16, max(by_size, (64 + B - 1) / B));
         NS = min(NS, want);
     }
     float *part = (float *)stats_ws;
