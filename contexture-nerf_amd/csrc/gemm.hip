@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmArgs a)
 //   5: 64x64 4w (32x32 per wave)   6: 64x64 2w (64x32)   7: 128x128 8w (32x64)   8: 64x128 4w (32x64)   9: 128x64 4w (64x32)
 //   10-18: 64-deep K stages, ring of 3: 256x128 16w (32x64) | 256x128 16w (64x32) | 256x128 8w | 128x128 16w (32x32) | 128x128 8w |
 //          64x64 4w | 64x128 4w | 128x64 4w | 128x128 4w;  19-22: ring of 2: 64x64 4w | 128x128 8w | 128x128 16w | 128x128 4w
-//   23-26: deep rings: 64x64 4w x6 | 64x128 4w x5 | 128x128 8w x4 | 128x64 4w x5
+//   23-26: deep rings: 64x64 4w x6 | 64x128 4w x5 | 128x128 8w x4 | 128x64 4w x5;  27: 256x320 8w (64x160), ring of 2
 static int g_force_tile = -1, g_force_gemm8 = -1;
 extern "C" void ctx_gemm_tune(int32_t tile, int32_t gemm8)
 {
@@ -459,14 +459,15 @@ static void launch_gemm(GemmArgs &a, hipStream_t s)
     a.mfast = mfast >= 0 ? mfast : (wbytes > xbytes ? 1 : 0);
     static int stg = -1;
     if (stg < 0) { const char *e = getenv("CTX_GEMM_STAGE_EPI"); stg = e ? atoi(e) : 1; }
-    a.stage_epi = stg && (a.ldc % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0);
+    a.stage_epi = stg && (a.ldc % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0) &&
+                  (size_t)WM * WN * 32 * (32 * NI + 4) * sizeof(float) <= 160 * 1024;       // the per-wave fp32 patch must fit the LDS
     static int steady = -1;
     if (steady < 0) { const char *e = getenv("CTX_GEMM_STEADY"); steady = e ? atoi(e) : 1; }
     a.pk = PKT; a.krot = steady ? 0 : 2;                 // krot = 2: no rotation, general K loop only (A/B switch of the steady loop)
     constexpr int NT = 64 * WM * WN;
     constexpr size_t ring = (size_t)NS * (BM + BN) * PKT * sizeof(f16);
     constexpr size_t patch = (size_t)WM * WN * 32 * (32 * NI + 4) * sizeof(float);
-    constexpr size_t lds = ring > patch ? ring : patch;
+    constexpr size_t lds = (ring > patch || patch > 160 * 1024) ? ring : patch;
     auto kern = k_gemm_pipe<WM, WN, MI, NI, CONV, NS, PKT>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -580,7 +581,7 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
         if (force == -2) { const char *e = getenv("CTX_GEMM_TILE"); force = e ? atoi(e) : -1; }
         if (force >= 0) pick = force;
         if (want_tile >= 0) pick = want_tile;
-        if (a.epi == 1 && (pick == 5 || pick == 6 || pick == 9 || pick == 11 || pick == 13 || pick == 15 || pick == 17 || pick == 19 || pick == 21 || pick == 23 || pick == 26)) pick = 1;   // GEGLU needs 64-wide wave tiles
+        if (a.epi == 1 && (pick == 5 || pick == 6 || pick == 9 || pick == 11 || pick == 13 || pick == 15 || pick == 17 || pick == 19 || pick == 21 || pick == 23 || pick == 26 || pick == 27)) pick = 1;   // GEGLU needs 64-wide wave tiles
         if (pick >= 10 && (a.K % 64 != 0 || (conv && a.Cin % 64 != 0))) pick = 1;   // 64-deep stages
 #define CTX_LAUNCH(WM_, WN_, MI_, NI_) do { if (conv) launch_gemm<WM_, WN_, MI_, NI_, true>(a, s); else launch_gemm<WM_, WN_, MI_, NI_, false>(a, s); } while (0)
         switch (pick) {
@@ -615,7 +616,8 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
         case 23: CTX_LAUNCH64NS(6, 2, 2, 1, 1); break;   // 64x64, 4 waves, ring of 6
         case 24: CTX_LAUNCH64NS(5, 2, 2, 1, 2); break;   // 64x128, 4 waves, ring of 5
         case 25: CTX_LAUNCH64NS(4, 4, 2, 1, 2); break;   // 128x128, 8 waves, ring of 4
-        default: CTX_LAUNCH64NS(5, 2, 2, 2, 1); break;   // 26: 128x64, 4 waves, ring of 5
+        case 26: CTX_LAUNCH64NS(5, 2, 2, 2, 1); break;   // 128x64, 4 waves, ring of 5
+        default: CTX_LAUNCH64N2(4, 2, 2, 5); break;      // 27: 256x320, 8 waves (64x160 each), ring of 2: 142 FLOP per staged byte (the lockstep batch)
 #undef CTX_LAUNCH64NS
 #undef CTX_LAUNCH64N2
 #undef CTX_LAUNCH64

@@ -98,7 +98,7 @@ def test_conv8_forced(dev, force_gemm8, B, H, W, Cin, Cout, stride, ups):
     test_conv3x3(dev, B, H, W, Cin, Cout, stride, ups)
 
 
-@pytest.mark.parametrize("tile", list(range(27)))
+@pytest.mark.parametrize("tile", list(range(28)))
 def test_every_tile_form(dev, tile):
     """Each tile form of gemm.hip forced through the tuning override: GEMM with ragged M / N and a convolution."""
     L, lib = _lib()

@@ -20,7 +20,7 @@ for (M, N, K) in [(4608, 640, 640), (18432, 320, 320), (1152, 1280, 1280), (4608
     want = x.float() @ w.float().T + b.float() + r.float()
     part = torch.empty(4 * M * N, dtype=torch.float32, device=dev)
     bad = []
-    for (tile, u8) in [(t, 0) for t in range(27)] + [(-1, 1), (-1, 4), (-1, 5), (-1, 6), (-1, 7)]:
+    for (tile, u8) in [(t, 0) for t in range(28)] + [(-1, 1), (-1, 4), (-1, 5), (-1, 6), (-1, 7)]:
         for S in (1, 2, 4):
             lib.ctx_gemm_tune(tile, u8)
             worst = 0

@@ -98,8 +98,8 @@ for s_ in shapes:
         rows.append((s_, best))
         continue
     for S in splits:
-        for tile in range(27):
-            if epi == 1 and tile in (5, 6, 9, 11, 13, 15, 17, 19, 21, 23, 26): continue
+        for tile in range(28):
+            if epi == 1 and tile in (5, 6, 9, 11, 13, 15, 17, 19, 21, 23, 26, 27): continue
             if tile >= 10 and (K % 64 or (s_[0] == 1 and Cin % 64)): continue
             t = run(tile, 0, S)
             if t: cands.append((t, tile, 0, S))
