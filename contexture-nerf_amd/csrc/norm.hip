@@ -12,9 +12,11 @@
 // GroupNorm.  Both passes are latency-bound at the UNet's sizes (a 12 MB tensor is ~2 HBM latencies deep), so the
 // structure is "every load of a thread in flight at once":
 // Pass 1: grid (NS, B), block = C/8 chunk columns x PL pixel lanes (~1000 threads); a thread owns 8 channels and
-// up to GN_U pixels of its split, all loaded before the first add; per-channel partials -> LDS -> per-group sums.
-// Pass 2: grid (nb, B); a thread issues its GN_AU 16-byte loads first, then the block folds the NS split partials
-// per (b, group) in a fixed order (deterministic: no float atomics anywhere in GroupNorm) while they fly.
+// walks its split GN_U pixels at a time, each batch loaded before its first add; per-channel partials -> LDS -> per-group
+// sums.  NS by sample size (16-32 for the UNet's tensors, 128 for the VAE's: see the launcher).
+// Pass 2: grid (nb, B), block = C/8 chunk columns x >= 256/(C/8) pixel lanes; a thread keeps ONE column (scale / shift in
+// registers), issues its GN_AU 16-byte loads first, then the block folds the NS split partials per (b, group) in a fixed
+// order (deterministic: no float atomics anywhere in GroupNorm) while they fly.
 // 8 consecutive channels of the input as floats: fp16 activations (16 bytes) or the fp32 residual stream (32 bytes)
 struct F8 { float v[8]; };
 template <bool X32>
