@@ -364,6 +364,42 @@ def test_attention_rescale_branch(dev):
     _close(o, want, rtol=3e-3, atol=3e-3, what="attention rescale")
 
 
+def test_attention_creeping_maximum_lazy_rescale(dev):
+    """The lazily updated maximum (attention.hip: O and l are rescaled only when some row's maximum moved by more than 2^8): scores that
+    rise a little with every key keep the subtracted maximum STALE for several tiles, so P runs up to 2^8 before a rescale; rows that
+    jump, rows that never move and a ragged last tile in the same workgroup.  Against float64 softmax, and against CTX_ATTN_LAZY=0
+    (rescale on every change) run in a child process: the two agree to fp16 rounding of P."""
+    import subprocess, sys, tempfile
+    L, lib = _lib()
+    B, S, Skv, heads = 1, 192, 1000, 2
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(B, S, heads * 64, generator=g).half()
+    k = (0.05 * torch.randn(B, Skv, heads * 64, generator=g)).half()
+    v = torch.randn(B, Skv, heads * 64, generator=g).half()
+    ramp = torch.linspace(0.0, 6.0, Skv)                                    # log2-scores creep up by ~0.4 per 64-key tile ...
+    k[0, :, :64] += (ramp[:, None] * q[0, 3:4, :64].float() / q[0, 3, :64].float().pow(2).sum() * 8 / 1.4427).half()
+    k[0, 700, 64:] = q[0, 9, 64:] * 5                                       # ... and one row of the other head jumps once
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    o = torch.empty(B, S, heads * 64, dtype=torch.float16, device=dev)
+    L.check(lib.ctx_attention_f16(L.ptr(qd), L.ptr(kd), L.ptr(vd), B, S, Skv, heads, heads * 64, heads * 64, 0.125, L.ptr(o), heads * 64, None, L.stream()))
+    qh = q.double().view(B, S, heads, 64).transpose(1, 2); kh = k.double().view(B, Skv, heads, 64).transpose(1, 2); vh = v.double().view(B, Skv, heads, 64).transpose(1, 2)
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(B, S, heads * 64)
+    assert torch.isfinite(o.float()).all()
+    _close(o, want, rtol=3e-3, atol=3e-3, what="attention, creeping maximum")
+    # the textbook recurrence in a fresh process (the threshold is read once per process)
+    with tempfile.TemporaryDirectory() as td:
+        torch.save({"q": q, "k": k, "v": v}, td + "/in.pt")
+        code = ("import torch, sys; sys.path.insert(0, %r); from contexture_nerf_amd import _lib as L; lib = L.load(); d = torch.load(%r); dev = torch.device('cuda:0');"
+                "q, k, v = (d[n].to(dev) for n in 'qkv'); o = torch.empty_like(q);"
+                "L.check(lib.ctx_attention_f16(L.ptr(q), L.ptr(k), L.ptr(v), 1, %d, %d, %d, %d, %d, 0.125, L.ptr(o), %d, None, L.stream())); torch.save(o.cpu(), %r)"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), td + "/in.pt", S, Skv, heads, heads * 64, heads * 64, heads * 64, td + "/out.pt"))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CTX_ATTN_LAZY="0"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        o0 = torch.load(td + "/out.pt")
+    d = (o.cpu().float() - o0.float()).abs()
+    assert float(d.max()) <= 4e-3 and float((d > 0).float().mean()) > 0.0, f"lazy vs eager rescale: max {float(d.max()):.3e}"
+
+
 def test_cfg_plms_scheduler(dev):
     from contexture_nerf_amd.scheduler import PNDMScheduler
     from oracle.scheduler import PNDMRef, cfg
