@@ -39,7 +39,7 @@ __device__ __forceinline__ F8 ld8(const void *base, size_t elem)
 #define GN_MAX_SPLITS 128
 #define GN_MAX_C 4096
 #define GN_U 4
-#define GN_AU 12
+#define GN_AU 6
 #define GN_AU32 6
 #define GN_FOLD 8
 
@@ -111,7 +111,9 @@ __global__ __launch_bounds__(1024) void k_gn_stats(const void *__restrict__ x, i
     }
 }
 
-// 8 consecutive channels as they lie in memory (converted at use: 12 chunks in flight cost 48 VGPRs as fp16, 96 as floats)
+// 8 consecutive channels as they lie in memory (converted at use: 4 VGPRs per chunk in flight as fp16, 8 as floats).  GN_AU = 6 chunks
+// per thread measured best over the UNet's shapes (4 / 6 / 8 / 12: 6.7 / 5.8 / 6.4 / 7.7 us at 2304 x 640 x batch 2, 9.0 / 9.2 / 10.5 / 9.5 at
+// 9216 x 320): with 12 a SIMD holds one wave whose ~1.7 us of SiLU arithmetic follows its loads instead of hiding under another wave's
 template <bool X32> struct Raw8;
 template <> struct Raw8<false> {
     f16x8 a;
