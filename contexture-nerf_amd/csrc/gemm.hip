@@ -556,7 +556,7 @@ int ctx_gemm_dispatch(GemmArgs &a, bool conv, hipStream_t s)
     if (only_pipe) a.use8 = 0;
     const int want8 = only_pipe ? 0 : (g_force_gemm8 >= 0 ? g_force_gemm8 : a.use8);          // -1: gemm8's own heuristic
     const int want_tile = g_force_tile >= 0 ? g_force_tile : (g_force_gemm8 >= 0 ? -1 : a.tile);
-    if (want_tile < 0 && want8 >= 4 && want8 <= 7 && ctx_gemm144_try(a, conv, want8 - 4, s)) {
+    if (want_tile < 0 && want8 >= 4 && want8 <= 8 && ctx_gemm144_try(a, conv, want8 - 4, s)) {
         if (a.splitk > 1) launch_reduce(a, s);
     } else if (want_tile < 0 && conv && (want8 == 2 || want8 == 3) && ctx_conv_halo_try(a, want8 == 2 ? 2 : 1, s)) {
         if (a.splitk > 1) launch_reduce(a, s);

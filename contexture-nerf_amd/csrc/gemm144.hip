@@ -38,11 +38,16 @@ __device__ __forceinline__ int g144_xcd_remap(int bid, int nwg)
 
 // UPS: the convolution has the fused nearest x2 upsample (generic per-tap address arithmetic); without it a tap is one scalar
 // offset from the lane's centre-tap pointer and a bit of a 9-bit in-bounds mask
-template <int WM, int WN, bool CONV, int NS, int VAR, bool UPS = false>
+// BMB: token rows of the tile in 16-row blocks: 9 (144 x 160) or 18 (288 x 160: 103 instead of 76 FLOP per staged byte, for problems
+// with >= ~512 such tiles, i.e. the lockstep batch; its 56 KB stages leave room for a ring of 2 only, so it runs the lockstep schedule)
+template <int WM, int WN, bool CONV, int NS, int VAR, bool UPS = false, int BMB = 9>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
 {
-    constexpr int NW = WM * WN, MI = 9 / WM, NI = 10 / WN;          // waves; 16x16 blocks per wave along tokens / features
-    constexpr int NP = 38;                                          // DMA pieces per stage: 18 activation + 20 weight (8 rows x 128 B)
+    constexpr int NW = WM * WN, MI = BMB / WM, NI = 10 / WN;        // waves; 16x16 blocks per wave along tokens / features
+    constexpr int BM = 16 * BMB, NPX = BM / 8;                      // tile rows; activation pieces (8 rows x 128 B each)
+    constexpr int NP = NPX + 20;                                    // DMA pieces per stage: activation + 20 weight
+    constexpr int STAGE = (BM + G144_BN) * 64;                      // f16 per stage
+    static_assert(BMB % WM == 0 && (BMB == 9 || (BMB == 18 && VAR == 0)), "288-row tiles: lockstep schedule only");
     constexpr int SL = (NP + NW - 1) / NW;                          // piece slots per wave (the last one empty on some waves)
     static_assert(9 % WM == 0 && 10 % WN == 0, "wave grid must divide 9 x 10 blocks");
     extern __shared__ __attribute__((aligned(16))) f16 smem[];     // [NS][144 X rows | 160 W rows][64]
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
     const int lin = g144_xcd_remap(blockIdx.x, ntiles * a.splitk);
     const int slice = lin / ntiles, bid = lin - slice * ntiles;
     const int tile_n = a.mfast ? bid / a.ntm : bid % a.ntn, tile_m = a.mfast ? bid % a.ntm : bid / a.ntn;
-    const int m0 = tile_m * G144_BM, n0 = tile_n * G144_BN;
+    const int m0 = tile_m * BM, n0 = tile_n * G144_BN;
     const int nk_all = a.K / 64;
     const int kbeg = (int)((long)nk_all * slice / a.splitk);
     const int nk = (int)((long)nk_all * (slice + 1) / a.splitk) - kbeg;
@@ -70,8 +75,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
 #pragma unroll
     for (int i = 0; i < SL; ++i) {
         const int p = wave + NW * i;
-        const bool isx = p < 18, live = p < NP;
-        const int s = isx ? 8 * p + prow : 8 * (p - 18) + prow;     // row inside the activation / weight tile
+        const bool isx = p < NPX, live = p < NP;
+        const int s = isx ? 8 * p + prow : 8 * (p - NPX) + prow;     // row inside the activation / weight tile
         xlc[i] = (pc ^ ((s >> 1) & 7)) * 8;
         xoff[i] = 0; xoy[i] = 0; xox[i] = 0;
         if (isx) {
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             const int soff = (dy * a.W + dx) * a.Cin + cur_c0;     // scalar: the same for every lane
 #pragma unroll
             for (int i = 0; i < SL; ++i) {
-                if (wave + NW * i >= 18) continue;
+                if (wave + NW * i >= NPX) continue;
                 const bool v = (xval[i] >> cur_tap) & 1;
                 pp[i] = v ? xcen[i] + soff : zp;
                 pst[i] = v ? 64 : 0;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
         const int Hv = a.H << a.ups, Wv = a.W << a.ups;
 #pragma unroll
         for (int i = 0; i < SL; ++i) {
-            if (wave + NW * i >= 18) continue;
+            if (wave + NW * i >= NPX) continue;
             const int iy = xoy[i] + dy, ix = xox[i] + dx;
             const bool ok = xok[i] && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
             pp[i] = ok ? a.X + xoff[i] + (((iy >> a.ups) * a.W + (ix >> a.ups)) * a.Cin) + c0 : zp;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
     auto issue_slot = [&](int buf, int i) {
         const int p = wave + NW * i;
         if (p < NP) {
-            __builtin_amdgcn_global_load_lds((g144_gptr_t)pp[i], (g144_lptr_t)(smem + buf * G144_STAGE + p * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((g144_gptr_t)pp[i], (g144_lptr_t)(smem + buf * STAGE + p * 512), 16, 0, 0);
             pp[i] += pst[i];
         }
     };
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
 
     const int swz = (r16 >> 1) & 7;
     const int ck[2] = {(kg ^ swz) * 8, ((4 + kg) ^ swz) * 8};
-    const int xrow = (wm * 16 * MI + r16) * 64, wrow = G144_BM * 64 + (wn * 16 * NI + r16) * 64;
+    const int xrow = (wm * 16 * MI + r16) * 64, wrow = BM * 64 + (wn * 16 * NI + r16) * 64;
 
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the barrier does not wait for LDS reads in flight (stage kt-1's)
             ctx_barrier();                                          // everybody's pieces landed AND everybody finished stage kt-1
             if (issued < nk) issue(buf == 0 ? NS - 1 : buf - 1);   // into the buffer stage kt-1 used
-            const f16 *sb = smem + buf * G144_STAGE;
+            const f16 *sb = smem + buf * STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 f16x8 xf[MI], wf[NI];
@@ -235,13 +240,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             ctx_barrier();                           // pair landed for everybody; the previous pair's buffers are free
             // quarter q of the pair: buffer b0 + (q >> 1), k half q & 1
-            rd(xa, wa, smem + b0 * G144_STAGE, 0);
+            rd(xa, wa, smem + b0 * STAGE, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q >= 2 && !two) break;
                 const bool even = (q & 1) == 0;
                 if (q + 1 < (two ? 4 : 2)) {
-                    const f16 *sn = smem + (b0 + ((q + 1) >> 1)) * G144_STAGE;
+                    const f16 *sn = smem + (b0 + ((q + 1) >> 1)) * STAGE;
                     if (even) rd(xb, wb, sn, (q + 1) & 1); else rd(xa, wa, sn, (q + 1) & 1);
                 }
                 // the next pair's two stages go into the buffers of the previous pair, one stage per even quarter
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             const bool go = ST || issued < nk;
             const int pb = buf == 0 ? NS - 1 : buf - 1;             // buffer of stage kt-1: takes stage kt+3
             const int nb_ = buf == NS - 1 ? 0 : buf + 1;
-            const f16 *sc = smem + buf * G144_STAGE, *sn = smem + nb_ * G144_STAGE;
+            const f16 *sc = smem + buf * STAGE, *sn = smem + nb_ * STAGE;
             const bool more = ST || kt + 1 < nk;
             if (go) issue_begin();
 #pragma unroll
@@ -373,38 +378,46 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
         float *tile = (float *)smem;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         ctx_barrier();                               // every wave is done with the ring
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                *(f32x4 *)(tile + (wm * 16 * MI + 16 * i + r16) * RS + wn * 16 * NI + 16 * j + 4 * kg) = acc[i][j];
-        __syncthreads();
         constexpr int NT = 64 * NW, CPR = G144_BN / 8;              // chunks of 8 features per row
-        for (int ch = tid; ch < G144_BM * CPR; ch += NT) {
-            const int row = ch / CPR, c8 = (ch - row * CPR) * 8;
-            const int m = m0 + row, n = n0 + c8;
-            if (m >= a.M || n >= a.N) continue;
-            const f32x4 v0 = *(const f32x4 *)(tile + row * RS + c8), v1 = *(const f32x4 *)(tile + row * RS + c8 + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            if (a.bias) {
-                const f16x8 bb = *(const f16x8 *)(a.bias + n);
+        // 144 rows at a time (the 288-row tile takes two passes through the same patch)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
+        for (int half = 0; half < BMB / 9; ++half) {
+            if (half) __syncthreads();                              // the previous pass has been read out
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int blk = wm * MI + i;                        // 16-row block of the tile
+                if (blk / 9 != half) continue;
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    *(f32x4 *)(tile + ((blk - 9 * half) * 16 + r16) * RS + wn * 16 * NI + 16 * j + 4 * kg) = acc[i][j];
             }
-            if (a.rowbias) {
-                const f16x8 bb = *(const f16x8 *)(a.rowbias + (size_t)(m / a.rows_per_batch) * a.ldrb + n);
+            __syncthreads();
+            for (int ch = tid; ch < 144 * CPR; ch += NT) {
+                const int row = ch / CPR, c8 = (ch - row * CPR) * 8;
+                const int m = m0 + 144 * half + row, n = n0 + c8;
+                if (m >= a.M || n >= a.N) continue;
+                const f32x4 v0 = *(const f32x4 *)(tile + row * RS + c8), v1 = *(const f32x4 *)(tile + row * RS + c8 + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (a.bias) {
+                    const f16x8 bb = *(const f16x8 *)(a.bias + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
+                    for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
+                }
+                if (a.rowbias) {
+                    const f16x8 bb = *(const f16x8 *)(a.rowbias + (size_t)(m / a.rows_per_batch) * a.ldrb + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
+                }
+                if (a.residual) {
+                    const f16x8 bb = *(const f16x8 *)(a.residual + (size_t)m * a.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
+                }
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+                *(f16x8 *)(a.out + (size_t)m * a.ldc + n) = o;
             }
-            if (a.residual) {
-                const f16x8 bb = *(const f16x8 *)(a.residual + (size_t)m * a.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
-            }
-            f16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-            *(f16x8 *)(a.out + (size_t)m * a.ldc + n) = o;
         }
         return;
     }
@@ -450,7 +463,8 @@ int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
 {
     if (a.K % 64 != 0 || (conv && a.Cin % 64 != 0) || a.N % 4 != 0 || a.epi != 0 || a.res32 || a.out32 || a.zins) return 0;
     if (a.ldc % 4 != 0 || (a.residual && a.ldr % 4 != 0) || (a.rowbias && a.ldrb % 4 != 0)) return 0;
-    a.ntm = cdiv(a.M, G144_BM);
+    const int bm = form == 4 ? 288 : G144_BM;
+    a.ntm = cdiv(a.M, bm);
     a.ntn = cdiv(a.N, G144_BN);
     int S = (a.splitk > 1 && a.part) ? a.splitk : 1;
     if (S > a.K / 64) S = a.K / 64;
@@ -460,9 +474,9 @@ int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
     static int stg = -1;
     if (stg < 0) { const char *e = getenv("CTX_G144_STAGE"); stg = e ? atoi(e) : 1; }
     a.stage_epi = stg && form != 0 && a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.residual || a.ldr % 8 == 0) && (!a.rowbias || a.ldrb % 8 == 0);
-    static bool attr[16] = {};
+    static bool attr[20] = {};
     auto go = [&](auto kern, int which, int threads, int ns) {
-        const size_t lds = (size_t)ns * G144_STAGE * sizeof(f16);
+        const size_t lds = (size_t)ns * (bm + G144_BN) * 64 * sizeof(f16);
         if (!attr[which]) {
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr[which] = true;
@@ -476,6 +490,10 @@ int ctx_gemm144_try(GemmArgs &a, bool conv, int form, hipStream_t s)
     };
     const bool ups = conv && a.ups;
     switch (form) {
+    case 4:                                                          // 288 x 160, 15 waves, lockstep, ring of 2
+        if (!conv) go(k_gemm144<3, 5, false, 2, 0, false, 18>, 12, 960, 2);
+        else if (ups) go(k_gemm144<3, 5, true, 2, 0, true, 18>, 13, 960, 2); else go(k_gemm144<3, 5, true, 2, 0, false, 18>, 14, 960, 2);
+        break;
     case 1:
         if (!conv) go(k_gemm144<3, 5, false, 3, 0>, 2, 960, 3);
         else if (ups) go(k_gemm144<3, 5, true, 3, 0, true>, 8, 960, 3); else go(k_gemm144<3, 5, true, 3, 0>, 3, 960, 3);

@@ -27,7 +27,7 @@ struct GemmArgs {
     int pk;                // K-stage depth chosen by the launcher (32 or 64)
     int krot;              // 1: per-workgroup K rotation (spreads concurrent accesses to shared operand rows); 2: no rotation and no
                            // steady-state K loop (CTX_GEMM_STEADY=0, the A/B switch of gemm.hip's branch-free loop)
-    int tile, use8;        // plan: tile id of gemm.hip (-1 = heuristic); use8: -1 heuristic, 0 gemm.hip, 1 gemm8.hip, 2 / 3 conv_halo.hip (128 / 64 features), 4 / 5 gemm144.hip (6 / 15 waves)
+    int tile, use8;        // plan: tile id of gemm.hip (-1 = heuristic); use8: -1 heuristic, 0 gemm.hip, 1 gemm8.hip, 2 / 3 conv_halo.hip (128 / 64 features), 4 .. 8 gemm144.hip (6 waves; 15 waves lockstep; pipelined; barrier per two stages; 288 x 160 lockstep)
     int stage_epi;         // 1: epilogue staged through LDS (whole-line stores / residual reads)
     int mfast;             // 1: consecutive workgroups walk M first (share the weight panel in their XCD's L2)
 };

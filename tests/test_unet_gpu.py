@@ -124,7 +124,7 @@ def test_conv_halo_forced(dev, ni, B, H, W, Cin, Cout):
         lib.ctx_gemm_tune(-1, -1)
 
 
-@pytest.mark.parametrize("form", [4, 5, 6, 7])
+@pytest.mark.parametrize("form", [4, 5, 6, 7, 8])
 def test_gemm144_forced(dev, form):
     """144x160 kernel, 6- and 15-wave forms (gemm144.hip) forced through the tuning override: whole and ragged tiles, bias + residual, the
     conv address generator (stride 1 / 2, fused x2 upsample, image borders) and fp32 split-K slabs."""

@@ -20,7 +20,7 @@ for (M, N, K) in [(4608, 640, 640), (18432, 320, 320), (1152, 1280, 1280), (4608
     want = x.float() @ w.float().T + b.float() + r.float()
     part = torch.empty(4 * M * N, dtype=torch.float32, device=dev)
     bad = []
-    for (tile, u8) in [(t, 0) for t in range(28)] + [(-1, 1), (-1, 4), (-1, 5), (-1, 6), (-1, 7)]:
+    for (tile, u8) in [(t, 0) for t in range(28)] + [(-1, 1), (-1, 4), (-1, 5), (-1, 6), (-1, 7), (-1, 8)]:
         for S in (1, 2, 4):
             lib.ctx_gemm_tune(tile, u8)
             worst = 0
@@ -44,7 +44,7 @@ for (B, H, W, Cin, Cout, flags) in [(2, 48, 48, 640, 640, 0), (2, 96, 96, 320, 3
     want = F.conv2d(xin, wt, b.float(), stride=st, padding=1).permute(0, 2, 3, 1).reshape(M, N) + r.float()
     part = torch.empty(4 * M * N, dtype=torch.float32, device=dev)
     bad = []
-    for (tile, u8) in [(t, 0) for t in (1, 5, 10, 12, 14, 15, 19, 20, 22, 25)] + [(-1, 1), (-1, 5), (-1, 6), (-1, 7)] + ([(-1, 2), (-1, 3)] if flags == 0 else []):
+    for (tile, u8) in [(t, 0) for t in (1, 5, 10, 12, 14, 15, 19, 20, 22, 25)] + [(-1, 1), (-1, 5), (-1, 6), (-1, 7), (-1, 8)] + ([(-1, 2), (-1, 3)] if flags == 0 else []):
         for S in (1, 2, 4):
             lib.ctx_gemm_tune(tile, u8)
             worst = 0

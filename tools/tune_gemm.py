@@ -107,7 +107,7 @@ for s_ in shapes:
             t = run(-1, 1, S)
             if t: cands.append((t, -1, 1, S))
         if epi == 0 and K % 64 == 0 and (s_[0] == 0 or Cin % 64 == 0) and (K // 64 // S) >= 1:
-            for u8 in (4, 5, 6, 7):                             # gemm144.hip: 144x160 tiles; 6 waves / 15 waves lockstep / pipelined / barrier per two stages
+            for u8 in (4, 5, 6, 7, 8):                          # gemm144.hip: 144x160 tiles; 6 waves / 15 waves lockstep / pipelined / barrier per two stages; 8: 288x160 lockstep
                 t = run(-1, u8, S)
                 if t: cands.append((t, -1, u8, S))
         if s_[0] == 1 and flags == 0 and H % 16 == 0 and W % 16 == 0 and Cin % 64 == 0 and S <= Cin // 64:
