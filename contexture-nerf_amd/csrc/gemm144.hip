@@ -190,7 +190,47 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm144(GemmArgs a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     int buf = 0;
-    if constexpr (VAR == 0) {
+    if constexpr (VAR == 0 && BMB == 18) {
+        // lockstep with the stage's own work interleaved (the 288-row tile: ring of 2, so nothing of the NEXT stage can be touched
+        // early): k 0..31 fragments first, then one DMA piece of the next stage behind each MFMA row instead of a burst of four at the
+        // barrier (the vector-memory port queues them: the attention kernel's time stamps), and the k 32..63
+        // fragments read under the first half's MFMAs.
+        f16x8 xa[MI], wa[NI], wb[NI];                               // the k 32..63 token fragments reuse xa row by row (128 VGPRs at 15 waves)
+        auto mrow = [&](const f16x8 &xf, const f16x8 (&wf)[NI], int i) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf, acc[i][j], 0, 0, 0);
+        };
+        static_assert(BMB != 18 || SL <= MI, "one DMA piece per MFMA row");
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_newer(issued - 1 - kt);                            // this wave's pieces of stage kt
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ctx_barrier();
+            const bool go = issued < nk;
+            const int pb = buf == 0 ? NS - 1 : buf - 1;
+            const f16 *sb = smem + buf * STAGE;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) xa[i] = *(const f16x8 *)(sb + xrow + i * 1024 + ck[0]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wa[j] = *(const f16x8 *)(sb + wrow + j * 1024 + ck[0]);
+            if (go) issue_begin();
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                mrow(xa[i], wa, i);
+                __builtin_amdgcn_sched_barrier(0);
+                xa[i] = *(const f16x8 *)(sb + xrow + i * 1024 + ck[1]);       // the row just consumed takes its second half
+                if (i == 0) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) wb[j] = *(const f16x8 *)(sb + wrow + j * 1024 + ck[1]);
+                }
+                if (go && i < SL) issue_slot(pb, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (go) issue_end();
+#pragma unroll
+            for (int i = 0; i < MI; ++i) mrow(xa[i], wb, i);
+            buf = buf == NS - 1 ? 0 : buf + 1;
+        }
+    } else if constexpr (VAR == 0) {
         // lockstep schedule: one barrier per stage, every wave issues, reads and multiplies in the same order
         for (int kt = 0; kt < nk; ++kt) {
             wait_newer(issued - 1 - kt);                            // this wave's pieces of stage kt
