@@ -527,6 +527,17 @@ void ctx_gemm_plan(GemmArgs &a, bool conv)
     // shapes outside the table: the rules the plan search kept producing (tools/tune_gemm.py, latents 96 / 64 / 32)
     if (a.K % 64 == 0 && (!conv || a.Cin % 64 == 0)) {
         const double MN = (double)a.M * a.N;
+        // Large plain-epilogue problems (other lockstep batch sizes than the tuned 2 and 12, other latent sizes): the 144 x 160 kernel
+        // family of gemm144.hip where it has enough tiles to fill the chip and little masked waste along N — the 288-row form from ~512
+        // tiles on, the software-pipelined 144-row form from ~220 (what the plan search chose for such shapes at batch 2 / 12).
+        if (a.epi == 0 && a.N % 8 == 0 && !a.zins && !a.res32 && !a.out32) {
+            const int nt = cdiv(a.N, 160);
+            const double fill = (double)a.N / (160.0 * nt);
+            if (fill >= 0.8) {
+                if (cdiv(a.M, 288) * nt >= 512) { a.tile = -1; a.use8 = 8; a.splitk = 1; return; }
+                if (cdiv(a.M, 144) * nt >= 220) { a.tile = -1; a.use8 = 6; a.splitk = 1; return; }
+            }
+        }
         int tile, bm, bn;
         if (MN >= 5.0e6) { tile = a.epi == 1 ? 10 : (conv ? 12 : 11); bm = 256; bn = 128; }          // 256x128, 8 / 16 waves
         else if ((MN >= 2.5e6 && a.K >= 960) || (conv && MN >= 1.2e6 && a.K >= 5760)) { tile = 14; bm = 128; bn = 128; }
