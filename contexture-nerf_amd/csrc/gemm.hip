@@ -528,12 +528,13 @@ void ctx_gemm_plan(GemmArgs &a, bool conv)
     if (a.K % 64 == 0 && (!conv || a.Cin % 64 == 0)) {
         const double MN = (double)a.M * a.N;
         // Large plain-epilogue problems (other lockstep batch sizes than the tuned 2 and 12, other latent sizes): the 144 x 160 kernel
-        // family of gemm144.hip where it has enough tiles to fill the chip and little masked waste along N — the 288-row form from ~512
+        // family of gemm144.hip where it has enough tiles to fill the chip and <= 10 % masked waste along N — the 288-row form from ~512
         // tiles on, the software-pipelined 144-row form from ~220 (what the plan search chose for such shapes at batch 2 / 12).
-        if (a.epi == 0 && a.N % 8 == 0 && !a.zins && !a.res32 && !a.out32) {
+        static const int heur144 = [] { const char *e = getenv("CTX_GEMM_HEUR144"); return e ? atoi(e) : 1; }();    // 0: the r2 rules only (A/B)
+        if (heur144 && a.epi == 0 && a.N % 8 == 0 && !a.zins && !a.res32 && !a.out32) {
             const int nt = cdiv(a.N, 160);
             const double fill = (double)a.N / (160.0 * nt);
-            if (fill >= 0.8) {
+            if (fill >= 0.9) {                                  // the UNet's widths (multiples of 160); the VAE's 128 / 256 / 512 would mask a fifth of every tile (measured: the SDS loop's VAE passes lose 1.5 ms)
                 if (cdiv(a.M, 288) * nt >= 512) { a.tile = -1; a.use8 = 8; a.splitk = 1; return; }
                 if (cdiv(a.M, 144) * nt >= 220) { a.tile = -1; a.use8 = 6; a.splitk = 1; return; }
             }
