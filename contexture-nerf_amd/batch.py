@@ -50,7 +50,7 @@ class MeshBatchPainter:
         infl = max(1, int(getattr(self.trainers[0].cfg.optim, 'views_in_flight', 3)))
         vpe = int(getattr(self.trainers[0].cfg.optim, 'views_per_eval', 0))
         if vpe > 1 and hasattr(diffusion, 'img2img_step_batched'):
-            infl = vpe                                                # one lockstep UNet evaluation of batch 2 x vpe per group
+            infl = 2 * vpe if len(mine) >= 2 * vpe else vpe          # lockstep groups of vpe views (batch 2 x vpe), two groups in flight
         if not hasattr(diffusion, 'img2img_step_multi'):
             infl = 1
         for j in range(0, len(mine), infl):
